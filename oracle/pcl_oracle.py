@@ -1,0 +1,270 @@
+"""ctypes binding of oracle/liboracle.so - TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module; the product package (pcl_amd) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_LIB = None
+
+c_i64 = C.c_int64
+c_f32p = C.POINTER(C.c_float)
+c_i32p = C.POINTER(C.c_int32)
+c_i64p = C.POINTER(C.c_int64)
+
+CORR_DTYPE = np.dtype([("index_query", np.int32), ("index_match", np.int32), ("distance", np.float32)])
+
+
+class IcpParams(C.Structure):
+    _fields_ = [
+        ("max_iterations", C.c_int),
+        ("ransac_iterations", C.c_int),
+        ("transformation_epsilon", C.c_double),
+        ("euclidean_fitness_epsilon", C.c_double),
+        ("max_correspondence_distance", C.c_double),
+        ("ransac_outlier_threshold", C.c_double),
+        ("min_correspondences", C.c_int),
+    ]
+
+
+class IcpStats(C.Structure):
+    _fields_ = [
+        ("iterations", C.c_int),
+        ("converged", C.c_int),
+        ("last_correspondences", C.c_int),
+        ("fitness_delta", C.c_double),
+    ]
+
+
+def build(force=False):
+    so = _HERE / "liboracle.so"
+    src = _HERE / "pcl_oracle.c"
+    if force or not so.exists() or (src.exists() and so.stat().st_mtime < src.stat().st_mtime):
+        subprocess.check_call(["make", "-C", str(_HERE), "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = _HERE / "liboracle.so"
+        if not so.exists():
+            build()
+        L = C.CDLL(str(so))
+        L.orc_knn_brute.restype = C.c_int
+        L.orc_knn_brute.argtypes = [c_f32p, c_i64, C.c_int, c_f32p, c_i64, C.c_int, C.c_int, c_i32p, c_f32p]
+        L.orc_radius_brute.restype = C.c_int
+        L.orc_radius_brute.argtypes = [c_f32p, c_i64, C.c_int, c_f32p, c_i64, C.c_int, C.c_float, C.c_uint32,
+                                       C.c_int, c_i64p, C.POINTER(c_i32p), C.POINTER(c_f32p)]
+        L.orc_free.argtypes = [C.c_void_p]
+        L.orc_tree_build.restype = C.c_void_p
+        L.orc_tree_build.argtypes = [c_f32p, c_i64, C.c_int, C.c_int]
+        L.orc_tree_free.argtypes = [C.c_void_p]
+        L.orc_tree_knn.restype = C.c_int
+        L.orc_tree_knn.argtypes = [C.c_void_p, c_f32p, c_i64, C.c_int, C.c_int, c_i32p, c_f32p, C.c_int]
+        L.orc_tree_radius.restype = C.c_int
+        L.orc_tree_radius.argtypes = [C.c_void_p, c_f32p, c_i64, C.c_int, C.c_float, C.c_uint32, C.c_int,
+                                      c_i64p, C.POINTER(c_i32p), C.POINTER(c_f32p), C.c_int]
+        L.orc_transform.argtypes = [c_f32p, c_i64, C.c_int, c_f32p]
+        L.orc_estimate_rigid_svd.argtypes = [c_f32p, C.c_int, c_i32p, c_f32p, C.c_int, c_i32p, c_i64, c_f32p]
+        L.orc_correspondences.restype = c_i64
+        L.orc_correspondences.argtypes = [c_f32p, c_i64, C.c_int, c_f32p, c_i64, C.c_int, C.c_double, C.c_int,
+                                          C.c_void_p]
+        for name in ("orc_reject_distance",):
+            getattr(L, name).restype = c_i64
+        L.orc_reject_distance.argtypes = [C.c_void_p, c_i64, C.c_float, C.c_void_p]
+        L.orc_reject_median.restype = c_i64
+        L.orc_reject_median.argtypes = [C.c_void_p, c_i64, C.c_double, C.c_void_p, C.POINTER(C.c_double)]
+        L.orc_reject_one_to_one.restype = c_i64
+        L.orc_reject_one_to_one.argtypes = [C.c_void_p, c_i64, C.c_void_p]
+        L.orc_reject_trimmed.restype = c_i64
+        L.orc_reject_trimmed.argtypes = [C.c_void_p, c_i64, C.c_float, C.c_uint, C.c_void_p]
+        L.orc_ransac_registration.restype = c_i64
+        L.orc_ransac_registration.argtypes = [c_f32p, c_i64, C.c_int, c_f32p, c_i64, C.c_int, c_i32p, c_i32p,
+                                              c_i64, C.c_double, C.c_int, c_i32p, c_f32p, C.POINTER(C.c_int)]
+        L.orc_icp_default_params.argtypes = [C.POINTER(IcpParams)]
+        L.orc_icp_align.restype = C.c_int
+        L.orc_icp_align.argtypes = [C.POINTER(IcpParams), c_f32p, c_i64, C.c_int, c_f32p, c_i64, C.c_int, c_f32p,
+                                    c_f32p, c_f32p, C.POINTER(IcpStats), C.c_int]
+        L.orc_fitness_score.restype = C.c_double
+        L.orc_fitness_score.argtypes = [c_f32p, c_i64, C.c_int, c_f32p, c_i64, C.c_int, c_f32p, C.c_double]
+        _LIB = L
+    return _LIB
+
+
+def _f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    assert a.ndim == 2 and a.shape[1] in (3, 4), a.shape
+    return a
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def knn_brute(pts, queries, k):
+    pts, queries = _f32(pts), _f32(queries)
+    n, nq = len(pts), len(queries)
+    ke = min(k, n)
+    idx = np.empty((nq, max(ke, 0)), np.int32)
+    d2 = np.empty((nq, max(ke, 0)), np.float32)
+    if ke > 0 and nq > 0:
+        lib().orc_knn_brute(_p(pts, c_f32p), n, pts.shape[1], _p(queries, c_f32p), nq, queries.shape[1], k,
+                            _p(idx, c_i32p), _p(d2, c_f32p))
+    return idx, d2
+
+
+def _collect(offsets, pi, pd):
+    total = int(offsets[-1])
+    idx = np.ctypeslib.as_array(pi, shape=(max(total, 1),))[:total].copy()
+    d2 = np.ctypeslib.as_array(pd, shape=(max(total, 1),))[:total].copy()
+    lib().orc_free(pi)
+    lib().orc_free(pd)
+    return offsets, idx, d2
+
+
+def radius_brute(pts, queries, radius, max_nn=0, sorted_results=True):
+    """radius is the (double) radius; r2 = float(radius*radius) as impl/kdtree_flann.hpp:140."""
+    pts, queries = _f32(pts), _f32(queries)
+    nq = len(queries)
+    offsets = np.zeros(nq + 1, np.int64)
+    pi, pd = c_i32p(), c_f32p()
+    r2 = np.float32(float(radius) * float(radius))
+    lib().orc_radius_brute(_p(pts, c_f32p), len(pts), pts.shape[1], _p(queries, c_f32p), nq, queries.shape[1],
+                           r2, max_nn, int(sorted_results), _p(offsets, c_i64p), C.byref(pi), C.byref(pd))
+    return _collect(offsets, pi, pd)
+
+
+class Tree:
+    """FLANN-style single kd-tree (CPU baseline)."""
+
+    def __init__(self, pts, leaf_max=15):
+        self.pts = _f32(pts)
+        self.h = lib().orc_tree_build(_p(self.pts, c_f32p), len(self.pts), self.pts.shape[1], leaf_max)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_tree_free(self.h)
+            self.h = None
+
+    def knn(self, queries, k, nthreads=1):
+        queries = _f32(queries)
+        nq = len(queries)
+        ke = min(k, len(self.pts))
+        idx = np.empty((nq, ke), np.int32)
+        d2 = np.empty((nq, ke), np.float32)
+        if ke > 0 and nq > 0:
+            lib().orc_tree_knn(self.h, _p(queries, c_f32p), nq, queries.shape[1], k, _p(idx, c_i32p),
+                               _p(d2, c_f32p), nthreads)
+        return idx, d2
+
+    def radius(self, queries, radius, max_nn=0, sorted_results=True, nthreads=1):
+        queries = _f32(queries)
+        nq = len(queries)
+        offsets = np.zeros(nq + 1, np.int64)
+        pi, pd = c_i32p(), c_f32p()
+        r2 = np.float32(float(radius) * float(radius))
+        lib().orc_tree_radius(self.h, _p(queries, c_f32p), nq, queries.shape[1], r2, max_nn, int(sorted_results),
+                              _p(offsets, c_i64p), C.byref(pi), C.byref(pd), nthreads)
+        return _collect(offsets, pi, pd)
+
+
+def transform(pts, T):
+    out = _f32(pts).copy()
+    T = np.ascontiguousarray(T, np.float32).reshape(16)
+    lib().orc_transform(_p(out, c_f32p), len(out), out.shape[1], _p(T, c_f32p))
+    return out
+
+
+def estimate_rigid_svd(src, tgt, sidx=None, tidx=None):
+    src, tgt = _f32(src), _f32(tgt)
+    n = len(sidx) if sidx is not None else len(src)
+    si = np.ascontiguousarray(sidx, np.int32) if sidx is not None else None
+    ti = np.ascontiguousarray(tidx, np.int32) if tidx is not None else None
+    T = np.zeros(16, np.float32)
+    lib().orc_estimate_rigid_svd(_p(src, c_f32p), src.shape[1], _p(si, c_i32p) if si is not None else None,
+                                 _p(tgt, c_f32p), tgt.shape[1], _p(ti, c_i32p) if ti is not None else None,
+                                 n, _p(T, c_f32p))
+    return T.reshape(4, 4)
+
+
+def correspondences(src, tgt, max_dist=float(np.sqrt(np.finfo(np.float64).max)), reciprocal=False):
+    src, tgt = _f32(src), _f32(tgt)
+    out = np.zeros(len(src), CORR_DTYPE)
+    n = lib().orc_correspondences(_p(src, c_f32p), len(src), src.shape[1], _p(tgt, c_f32p), len(tgt),
+                                  tgt.shape[1], max_dist, int(reciprocal), out.ctypes.data)
+    return out[:n].copy()
+
+
+def reject_distance(corr, max_dist):
+    corr = np.ascontiguousarray(corr, CORR_DTYPE)
+    out = np.zeros(len(corr), CORR_DTYPE)
+    n = lib().orc_reject_distance(corr.ctypes.data, len(corr), max_dist, out.ctypes.data)
+    return out[:n].copy()
+
+
+def reject_median(corr, factor=1.0):
+    corr = np.ascontiguousarray(corr, CORR_DTYPE)
+    out = np.zeros(len(corr), CORR_DTYPE)
+    med = C.c_double(0)
+    n = lib().orc_reject_median(corr.ctypes.data, len(corr), factor, out.ctypes.data, C.byref(med))
+    return out[:n].copy(), med.value
+
+
+def reject_one_to_one(corr):
+    corr = np.ascontiguousarray(corr, CORR_DTYPE)
+    out = np.zeros(len(corr), CORR_DTYPE)
+    n = lib().orc_reject_one_to_one(corr.ctypes.data, len(corr), out.ctypes.data)
+    return out[:n].copy()
+
+
+def reject_trimmed(corr, overlap=0.5, min_corr=0):
+    corr = np.ascontiguousarray(corr, CORR_DTYPE)
+    out = np.zeros(len(corr), CORR_DTYPE)
+    n = lib().orc_reject_trimmed(corr.ctypes.data, len(corr), overlap, min_corr, out.ctypes.data)
+    return out[:n].copy()
+
+
+def ransac_registration(src, tgt, sidx, tidx, inlier_threshold, max_iterations=1000):
+    src, tgt = _f32(src), _f32(tgt)
+    si = np.ascontiguousarray(sidx, np.int32)
+    ti = np.ascontiguousarray(tidx, np.int32)
+    pos = np.zeros(len(si), np.int32)
+    T = np.zeros(16, np.float32)
+    trials = C.c_int(0)
+    n = lib().orc_ransac_registration(_p(src, c_f32p), len(src), src.shape[1], _p(tgt, c_f32p), len(tgt),
+                                      tgt.shape[1], _p(si, c_i32p), _p(ti, c_i32p), len(si), inlier_threshold,
+                                      max_iterations, _p(pos, c_i32p), _p(T, c_f32p), C.byref(trials))
+    return (pos[:n].copy() if n >= 0 else None), T.reshape(4, 4), trials.value
+
+
+def icp_default_params():
+    p = IcpParams()
+    lib().orc_icp_default_params(C.byref(p))
+    return p
+
+
+def icp_align(src, tgt, params=None, guess=None, nthreads=1):
+    src, tgt = _f32(src), _f32(tgt)
+    p = params or icp_default_params()
+    T = np.zeros(16, np.float32)
+    out = np.zeros((len(src), 4), np.float32)
+    st = IcpStats()
+    g = np.ascontiguousarray(guess, np.float32).reshape(16) if guess is not None else None
+    rc = lib().orc_icp_align(C.byref(p), _p(src, c_f32p), len(src), src.shape[1], _p(tgt, c_f32p), len(tgt),
+                             tgt.shape[1], _p(g, c_f32p) if g is not None else None, _p(T, c_f32p),
+                             _p(out, c_f32p), C.byref(st), nthreads)
+    return rc, T.reshape(4, 4), out, st
+
+
+def fitness_score(src, tgt, T, max_range=float(np.finfo(np.float64).max)):
+    src, tgt = _f32(src), _f32(tgt)
+    T = np.ascontiguousarray(T, np.float32).reshape(16)
+    return lib().orc_fitness_score(_p(src, c_f32p), len(src), src.shape[1], _p(tgt, c_f32p), len(tgt),
+                                   tgt.shape[1], _p(T, c_f32p), max_range)

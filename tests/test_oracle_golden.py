@@ -1,0 +1,148 @@
+"""Pins the CPU oracle against every golden vector the reference's tests hold for this path."""
+import numpy as np
+import pytest
+
+from oracle import pcl_oracle as orc
+from tests import util
+
+
+def test_kdtree_known_answer_10_points():
+    # test/kdtree/test_kdtree.cpp:336-398 (three point representations)
+    kat = util.golden("kdtree_kat.json")
+    pts = np.array(kat["points"], np.float32)
+    q = np.array([kat["query"]], np.float32)
+    for case in kat["cases"]:
+        alpha = np.array(case["alpha"], np.float32)
+        p = pts * alpha
+        qq = q * alpha
+        if case["dims"] == 2:  # unused dimension contributes (0-0)^2 = 0 exactly
+            p = p.copy(); p[:, 2] = 0
+            qq = qq.copy(); qq[:, 2] = 0
+        for fn in (orc.knn_brute, lambda a, b, k: orc.Tree(a).knn(b, k)):
+            idx, d2 = fn(p, qq, kat["k"])
+            assert idx[0].tolist() == case["indices"], case["name"]
+            assert np.allclose(d2[0], case["distances"], atol=kat["distance_tol"])
+
+
+def test_bun_correspondences_original_and_reciprocal():
+    api = util.golden("registration_api.json")
+    src, tgt = util.bun0(), util.bun4()
+    assert src.shape == (397, 3) and tgt.shape == (361, 3)
+    corr = orc.correspondences(src, tgt)
+    exp = np.array(api["correspondences_original"])
+    assert corr["index_query"].tolist() == exp[:, 0].tolist()
+    assert corr["index_match"].tolist() == exp[:, 1].tolist()
+    rec = orc.correspondences(src, tgt, reciprocal=True)
+    exp = np.array(api["correspondences_reciprocal"])
+    assert rec["index_query"].tolist() == exp[:, 0].tolist()
+    assert rec["index_match"].tolist() == exp[:, 1].tolist()
+    # brute force agrees with the tree
+    bi, bd = orc.knn_brute(tgt, src, 1)
+    assert bi[:, 0].tolist() == corr["index_match"].tolist()
+    assert np.array_equal(bd[:, 0], corr["distance"])
+
+
+def test_bun_rejectors():
+    api = util.golden("registration_api.json")
+    src, tgt = util.bun0(), util.bun4()
+    corr = orc.correspondences(src, tgt)
+    rd = orc.reject_distance(corr, api["rej_dist_max_dist"])
+    exp = np.array(api["correspondences_dist"])
+    assert rd["index_query"].tolist() == exp[:, 0].tolist()
+    assert rd["index_match"].tolist() == exp[:, 1].tolist()
+    oo = orc.reject_one_to_one(corr)
+    exp = np.array(api["correspondences_one_to_one"])
+    assert oo["index_match"].tolist() == exp[:, 1].tolist()
+    assert oo["index_query"].tolist() == exp[:, 0].tolist()
+    tr = orc.reject_trimmed(corr, api["rej_trimmed_overlap"])
+    exp = np.array(api["correspondences_trimmed"])
+    assert tr["index_query"].tolist() == exp[:, 0].tolist()
+    assert tr["index_match"].tolist() == exp[:, 1].tolist()
+    # median rejector: the reference test only checks it conditionally; check the definition
+    md, med = orc.reject_median(corr, 0.5)
+    d = np.sort(corr["distance"].astype(np.float64))
+    assert med == d[len(d) // 2]
+    assert len(md) == int((corr["distance"].astype(np.float64) <= med * 0.5).sum())
+
+
+def test_bun_ransac_rejector_and_transform():
+    api = util.golden("registration_api.json")
+    src, tgt = util.bun0(), util.bun4()
+    corr = orc.correspondences(src, tgt)
+    pos, T, trials = orc.ransac_registration(src, tgt, corr["index_query"], corr["index_match"],
+                                             api["rej_sac_max_dist"], api["rej_sac_max_iter"])
+    exp = np.array(api["correspondences_sac"])
+    assert pos is not None and len(pos) == len(exp)
+    # the reference test (test_registration_api.cpp:207-210) checks index_match only; the
+    # table's index_query column is stale in the reference data and is not reproduced
+    assert corr["index_match"][pos].tolist() == exp[:, 1].tolist()
+    assert np.allclose(T, np.array(api["transform_from_SAC"]), atol=1e-4)
+    assert trials > 0
+
+
+def test_bun_transformation_estimation_svd():
+    api = util.golden("registration_api.json")
+    src, tgt = util.bun0(), util.bun4()
+    rec = orc.correspondences(src, tgt, reciprocal=True)
+    T = orc.estimate_rigid_svd(src, tgt, rec["index_query"], rec["index_match"])
+    assert np.allclose(T, np.array(api["transform_from_SVD"]), atol=1e-4)
+
+
+@pytest.mark.parametrize("ransac", [1000, 0])
+def test_bun_full_icp(ransac):
+    # test/registration/test_registration.cpp:154-188
+    g = util.golden("icp_bun0_bun4.json")
+    src, tgt = util.bun0(), util.bun4()
+    p = orc.icp_default_params()
+    p.max_iterations = g["max_iterations"]
+    p.transformation_epsilon = g["transformation_epsilon"]
+    p.max_correspondence_distance = g["max_correspondence_distance"]
+    p.ransac_iterations = ransac
+    rc, T, out, st = orc.icp_align(src, tgt, p)
+    assert rc == 0 and st.converged
+    gold, tol = np.array(g["matrix"]), np.array(g["tol"])
+    assert np.all(np.abs(T[:3] - gold[:3]) <= tol[:3]), (T, gold)
+    assert T[3].tolist() == [0, 0, 0, 1]
+    assert out.shape == (397, 4)
+    # registered cloud == final transform applied to the source (within fp32 chain rounding)
+    assert np.allclose(out[:, :3], orc.transform(src, T), atol=1e-5)
+
+
+def test_tree_matches_brute_force_with_ties():
+    # 11^3 grid (test_kdtree.cpp:65-71): massive distance ties; (d2, index) order must agree
+    pts = util.grid_cloud()
+    assert len(pts) == 1331
+    q = np.array([[0.01, 0.01, 0.01], [0, 0, 0], [0.05, 0.05, 0.05], [-0.5, -0.5, -0.5]], np.float32)
+    t = orc.Tree(pts)
+    for k in (1, 8, 20, 64, 512, 1331, 5000):
+        bi, bd = orc.knn_brute(pts, q, k)
+        ti, td = t.knn(q, k)
+        assert np.array_equal(bi, ti) and np.array_equal(bd, td), k
+        assert np.all(np.diff(bd, axis=1) >= 0)
+    # radius 0.15 around the origin, strict < (test_kdtree.cpp:100-131)
+    off, ri, rd = t.radius(q[1:2], 0.15, max_nn=100)
+    d = np.sqrt(((pts.astype(np.float64) - 0.0) ** 2).sum(1))
+    # same comparison the reference test makes (euclideanDistance < max_dist) up to fp32 rounding
+    assert set(ri.tolist()) == set(np.nonzero(((pts * pts).sum(1, dtype=np.float32)) < np.float32(0.15 * 0.15))[0].tolist())
+    assert len(ri) <= 100 and abs(len(ri) - int((d < 0.15).sum())) <= 0
+    bo, bi, bd = orc.radius_brute(pts, q, 0.15)
+    to, ti, td = t.radius(q, 0.15)
+    assert np.array_equal(bo, to) and np.array_equal(bi, ti) and np.array_equal(bd, td)
+
+
+def test_tree_vs_brute_random_dense_and_radius_variants():
+    # recipe of test/test_search.cpp:571-617: 1200 uniform [0,1) points
+    pts = util.uniform_cloud(1200, 7)
+    q = util.uniform_cloud(64, 8)
+    t = orc.Tree(pts)
+    for k in (1, 8, 64, 512):
+        bi, bd = orc.knn_brute(pts, q, k)
+        ti, td = t.knn(q, k, nthreads=4)
+        assert np.array_equal(bi, ti) and np.array_equal(bd, td)
+    for r in (0.01, 0.02, 0.04, 0.08):
+        for max_nn, srt in ((0, True), (0, False), (5, True), (5, False)):
+            bo, bi, bd = orc.radius_brute(pts, q, r, max_nn, srt)
+            to, ti, td = t.radius(q, r, max_nn, srt, nthreads=4)
+            assert np.array_equal(bo, to) and np.array_equal(bi, ti) and np.array_equal(bd, td)
+            if max_nn:
+                assert np.all(np.diff(bo) <= max_nn)
