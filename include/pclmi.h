@@ -1,0 +1,219 @@
+/*
+ * pclmi.h - C ABI of the MI355X-native kNN / radius-search / ICP hot path.
+ *
+ * This is the drop-in boundary: the PCL-shaped C++ facade under include/pcl/ (and the
+ * ctypes binding in pcl_amd/) call ONLY these entry points.  Every entry point cites the
+ * reference interface it replaces (paths relative to the reference tree).  The reference
+ * has no FFI on this path - it is C++ virtual classes over FLANN - so the symbols below
+ * are what a binding of that path needs: plain pointers and sizes, int status codes, no
+ * C++ types, no exceptions.  See INTEGRATION.md for the reference-side stub.
+ *
+ * Conventions
+ *  - Points are float32 xyz at a byte stride (12 for packed xyz, 16 for pcl::PointXYZ,
+ *    common/include/pcl/impl/point_types.hpp:141-155).  Only the first three floats are read.
+ *  - Entry points without a _dev suffix take HOST pointers and copy; _dev entry points take
+ *    DEVICE pointers (inputs already resident in HBM) and enqueue on `stream`
+ *    (a hipStream_t passed as void*, NULL = the library's stream for that tree).
+ *  - Squared L2 distances are fp32, computed as ((dx*dx + dy*dy) + dz*dz) with one rounding
+ *    per operation (flann::L2_Simple<float>, kdtree/include/pcl/kdtree/kdtree_flann.h:56).
+ *  - Neighbour lists are ascending in the total order (d2, index): exact search, eps = 0,
+ *    ties broken by the lowest index.
+ *  - Return value: PCLMI_OK (0) or a pclmi_status error; pclmi_last_error() gives text.
+ *    There is NO CPU fallback: without a usable HIP device every compute call fails with
+ *    PCLMI_ERR_NO_DEVICE.
+ *  - All calls taking a `const pclmi_tree*` are thread-safe and re-entrant, as the
+ *    reference's const search methods are (features/.../impl/normal_3d_omp.hpp:62-68).
+ */
+#ifndef PCLMI_H_
+#define PCLMI_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  PCLMI_OK = 0,
+  PCLMI_ERR_INVALID = 1,     /* bad argument (null pointer, k <= 0, stride < 12, ...) */
+  PCLMI_ERR_NO_DEVICE = 2,   /* no HIP device / device init failed */
+  PCLMI_ERR_HIP = 3,         /* a HIP runtime call failed */
+  PCLMI_ERR_OOM = 4,         /* host or device allocation failed */
+  PCLMI_ERR_UNSUPPORTED = 5, /* valid request outside what this build implements */
+  PCLMI_ERR_NOT_ENOUGH = 6   /* ICP: fewer than min_correspondences pairs (icp.hpp:103-108) */
+} pclmi_status;
+
+typedef struct pclmi_tree pclmi_tree;
+
+/* Library / device ------------------------------------------------------------------ */
+const char *pclmi_version(void);
+const char *pclmi_last_error(void); /* thread-local text of the last failure */
+/* Number of visible HIP devices (0 when none; never fails). */
+int pclmi_device_count(void);
+/* Select the device used by subsequently created trees in this thread (default 0). */
+int pclmi_set_device(int device);
+
+/* Index build ------------------------------------------------------------------------
+ * Replaces pcl::KdTreeFLANN::setInputCloud + convertCloudToArray
+ * (kdtree/include/pcl/kdtree/impl/kdtree_flann.hpp:46-75,180-249).
+ * xyz/n/stride_bytes describe the WHOLE cloud.  indices (nullable, n_indices entries)
+ * selects the rows to index, as the IndicesConstPtr overload does (:214-249); returned
+ * neighbour indices are always rows of the whole cloud (the reference's index_mapping_).
+ * Rows with a non-finite coordinate are skipped (:199-203).  The cloud is copied: later
+ * edits do not affect the tree.  leaf_max <= 0 selects the default bucket size.
+ * An empty cloud yields a valid empty tree (searches return 0 neighbours). */
+int pclmi_tree_create(const float *xyz, size_t n, size_t stride_bytes, const int32_t *indices,
+                      size_t n_indices, int leaf_max, pclmi_tree **out);
+void pclmi_tree_destroy(pclmi_tree *t);
+/* Number of indexed (finite, selected) points = total_nr_points_ (:70). */
+size_t pclmi_tree_size(const pclmi_tree *t);
+
+/* k-nearest neighbours ---------------------------------------------------------------
+ * Replaces pcl::KdTreeFLANN::nearestKSearch (impl/kdtree_flann.hpp:78-112) and the batched
+ * pcl::search::Search::nearestKSearch loops (search/include/pcl/search/search.h:244-262).
+ * k is clamped to pclmi_tree_size (:85-86); *k_eff (nullable) receives the clamped value.
+ * idx / d2 hold nq * k_eff entries, row-major per query, ascending by (d2, index).
+ * Queries must be finite (the reference asserts, :83); a non-finite query yields
+ * index -1 / distance NaN rows. */
+int pclmi_knn(const pclmi_tree *t, const float *queries, size_t nq, size_t q_stride_bytes, int k,
+              int32_t *idx, float *d2, int *k_eff);
+/* Same with device-resident queries and outputs.  The row pitch of idx / d2 is
+ * min(k, pclmi_tree_size) entries. */
+int pclmi_knn_dev(const pclmi_tree *t, const float *d_queries, size_t nq, size_t q_stride_bytes,
+                  int k, int32_t *d_idx, float *d_d2, void *stream);
+
+/* Radius search ----------------------------------------------------------------------
+ * Replaces pcl::KdTreeFLANN::radiusSearch (impl/kdtree_flann.hpp:115-157) and the batched
+ * loops (search.h:412-434).  A neighbour qualifies iff d2 < (float)(radius*radius)
+ * (strict; the double product cast to float is the reference's, :140).  max_nn == 0 or
+ * > size returns all (:125-135), otherwise the nearest max_nn.  sorted != 0: ascending
+ * (d2, index) (setSortedResults, kdtree_flann.h:138-144); sorted == 0: ascending index.
+ * offsets has nq + 1 entries (CSR).  *idx / *d2 are allocated by the library (host
+ * memory, offsets[nq] entries each) and released with pclmi_free. */
+int pclmi_radius(const pclmi_tree *t, const float *queries, size_t nq, size_t q_stride_bytes,
+                 double radius, uint32_t max_nn, int sorted, uint64_t *offsets, int32_t **idx,
+                 float **d2);
+/* Device-resident variant: d_offsets has nq + 1 entries; *d_idx / *d_d2 are DEVICE
+ * buffers allocated by the library (release with pclmi_free_dev); *total receives
+ * offsets[nq].  Synchronises `stream` once (the output size is data dependent). */
+int pclmi_radius_dev(const pclmi_tree *t, const float *d_queries, size_t nq, size_t q_stride_bytes,
+                     double radius, uint32_t max_nn, int sorted, uint64_t *d_offsets,
+                     int32_t **d_idx, float **d_d2, uint64_t *total, void *stream);
+void pclmi_free(void *host_ptr);
+void pclmi_free_dev(void *device_ptr);
+
+/* Correspondence estimation ---------------------------------------------------------
+ * pcl::Correspondence {index_query, index_match, distance}
+ * (common/include/pcl/correspondence.h:53-75). */
+typedef struct {
+  int32_t index_query;
+  int32_t index_match;
+  float distance;
+} pclmi_correspondence;
+
+/* Replaces CorrespondenceEstimation::determineCorrespondences
+ * (registration/include/pcl/registration/impl/correspondence_estimation.hpp:83-141):
+ * 1-NN of every source point in the target tree, kept iff d2 <= max_distance^2
+ * (non-strict, :108).  src_indices (nullable) selects source rows (PCLBase indices_).
+ * out has capacity n_src (or n_indices); *n_out receives the count, in source order. */
+int pclmi_correspondences(const pclmi_tree *target, const float *src, size_t n_src,
+                          size_t stride_bytes, const int32_t *src_indices, size_t n_indices,
+                          double max_distance, pclmi_correspondence *out, size_t *n_out);
+/* Replaces determineReciprocalCorrespondences (:144-233): additionally requires the 1-NN of
+ * the matched target point in `source_tree` (built over the same source rows) to be the
+ * source point itself.  `tgt` is the target cloud the target tree was built from. */
+int pclmi_correspondences_reciprocal(const pclmi_tree *target, const pclmi_tree *source_tree,
+                                     const float *src, size_t n_src, size_t src_stride_bytes,
+                                     const int32_t *src_indices, size_t n_indices,
+                                     const float *tgt, size_t n_tgt, size_t tgt_stride_bytes,
+                                     double max_distance, pclmi_correspondence *out,
+                                     size_t *n_out);
+
+/* Rigid transform from paired points ------------------------------------------------
+ * Replaces TransformationEstimationSVD::estimateRigidTransformation
+ * (registration/include/pcl/registration/impl/transformation_estimation_svd.hpp:81-168):
+ * centroids, 3x3 cross-covariance H = sum (s - cs)(t - ct)', SVD, R = V U' with the
+ * determinant fix, t = ct - R cs.  The sums are reduced on the GPU in fp64 (one-pass
+ * moments), the 3x3 SVD runs on the host in fp64.  T is row-major 4x4 fp32.
+ * src_idx / tgt_idx (n entries) index rows of src / tgt (the pcl::Correspondences
+ * overload, :101-111); either may be NULL meaning 0..n-1. */
+int pclmi_estimate_rigid_svd(const float *src, size_t n_src, size_t src_stride_bytes,
+                             const int32_t *src_idx, const float *tgt, size_t n_tgt,
+                             size_t tgt_stride_bytes, const int32_t *tgt_idx, size_t n,
+                             float T[16]);
+
+/* p <- R p + t in fp32 (common/include/pcl/common/impl/transforms.hpp:168-206); rows with a
+ * non-finite coordinate are left untouched (the !is_dense branch, :196-204). */
+int pclmi_transform(float *xyz, size_t n, size_t stride_bytes, const float T[16]);
+
+/* Iterative Closest Point ------------------------------------------------------------
+ * Replaces pcl::IterativeClosestPoint::align / computeTransformation
+ * (registration/include/pcl/registration/impl/registration.hpp:119-168,
+ *  registration/include/pcl/registration/impl/icp.hpp:44-211). */
+typedef struct {
+  int max_iterations;                 /* registration.h:97, default 10 */
+  int ransac_iterations;              /* icp.h:104, default 1000; 0 skips the RANSAC step */
+  double transformation_epsilon;      /* default 0 */
+  double euclidean_fitness_epsilon;   /* default -DBL_MAX (never fires) */
+  double max_correspondence_distance; /* default sqrt(DBL_MAX) */
+  double ransac_outlier_threshold;    /* inlier_threshold_, default 0.05 */
+  int min_correspondences;            /* default 3 */
+} pclmi_icp_params;
+
+typedef struct {
+  int iterations;
+  int converged;
+  int last_correspondences; /* pairs under the distance threshold in the last iteration */
+  int last_inliers;         /* pairs used for the last transform (after RANSAC) */
+  double fitness_delta;     /* mean(d_now - d_prev) of the last iteration (registration.hpp:60-68) */
+  double transform_delta;   /* sum |T - T_prev| of the last iteration (icp.hpp:194) */
+} pclmi_icp_stats;
+
+void pclmi_icp_default_params(pclmi_icp_params *p);
+
+/* One call = Registration::align(output, guess).  `target` must have been built from the
+ * target cloud (Registration::setInputTarget, registration.hpp:41-57).  src is not
+ * modified.  guess may be NULL (identity).  aligned (nullable) receives n_src points at
+ * 16-byte stride (x, y, z, 1).  Returns PCLMI_ERR_NOT_ENOUGH when an iteration finds fewer
+ * than min_correspondences pairs (converged stays 0, as icp.hpp:103-108). */
+int pclmi_icp_align(const pclmi_icp_params *p, const pclmi_tree *target, const float *src,
+                    size_t n_src, size_t stride_bytes, const float *guess, float final_T[16],
+                    float *aligned, pclmi_icp_stats *stats);
+
+/* Registration::getFitnessScore(max_range) (registration.hpp:71-109): mean squared 1-NN
+ * distance of the transformed source, over pairs with d2 <= max_range, fp64 accumulate.
+ * Returns DBL_MAX in *score when no pair qualifies. */
+int pclmi_fitness_score(const pclmi_tree *target, const float *src, size_t n_src,
+                        size_t stride_bytes, const float T[16], double max_range, double *score);
+
+/* Sharded ICP (one process per GPU) ---------------------------------------------------
+ * The iteration is split so that a host-side driver can insert ONE all-reduce of the
+ * PCLMI_ICP_NSUMS fp64 partial sums between the GPU step and the SVD:
+ *   ctx = pclmi_icp_begin(target, src_shard)           uploads + Morton-sorts the shard
+ *   loop: pclmi_icp_step_dev(ctx, thr2, d_sums)        apply pending T, 1-NN, threshold,
+ *                                                      fp64 block reduce -> d_sums (device)
+ *         [all-reduce d_sums across ranks - RCCL via torch.distributed]
+ *         pclmi_icp_solve(h_sums, T)                   host: centroids, H, SVD -> T
+ *         pclmi_icp_set_transform(ctx, T)              T is applied at the next step / end
+ *   pclmi_icp_end(ctx, aligned)                         final transform + download + free
+ * pclmi_icp_solve needs no GPU and is the same code pclmi_icp_align runs per iteration. */
+#define PCLMI_ICP_NSUMS 24
+/* sums layout: [0] n_pairs, [1..3] sum s, [4..6] sum t, [7..15] sum s t' (row-major),
+ * [16] sum min(d2, thr2) over ALL points, [17] sum (d_now - d_prev) over ALL points,
+ * [18] n_points, [19..23] reserved (zero). */
+typedef struct pclmi_icp_ctx pclmi_icp_ctx;
+int pclmi_icp_begin(const pclmi_tree *target, const float *src, size_t n_src, size_t stride_bytes,
+                    const float *guess, pclmi_icp_ctx **out);
+int pclmi_icp_step_dev(pclmi_icp_ctx *ctx, double max_correspondence_distance, double *d_sums,
+                       void *stream);
+int pclmi_icp_step(pclmi_icp_ctx *ctx, double max_correspondence_distance,
+                   double h_sums[PCLMI_ICP_NSUMS]);
+int pclmi_icp_solve(const double sums[PCLMI_ICP_NSUMS], float T[16]);
+int pclmi_icp_set_transform(pclmi_icp_ctx *ctx, const float T[16]);
+int pclmi_icp_end(pclmi_icp_ctx *ctx, float *aligned);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCLMI_H_ */

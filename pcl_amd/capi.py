@@ -1,0 +1,317 @@
+"""ctypes binding of libpclmi.so (include/pclmi.h).  Plumbing only: every function here
+forwards to one C-ABI entry point; numpy arrays are host buffers, torch CUDA tensors are
+device buffers (passed by data_ptr()).
+"""
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "lib" / "libpclmi.so"
+_LIB = None
+
+STATUS = {0: "OK", 1: "INVALID", 2: "NO_DEVICE", 3: "HIP", 4: "OOM", 5: "UNSUPPORTED", 6: "NOT_ENOUGH"}
+ICP_NSUMS = 24
+
+CORR_DTYPE = np.dtype([("index_query", np.int32), ("index_match", np.int32), ("distance", np.float32)])
+
+c_f32p = C.POINTER(C.c_float)
+c_i32p = C.POINTER(C.c_int32)
+c_u64p = C.POINTER(C.c_uint64)
+c_f64p = C.POINTER(C.c_double)
+
+
+class PclmiError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("pclmi: %s (%s)" % (msg, STATUS.get(code, code)))
+        self.code = code
+
+
+class IcpParams(C.Structure):
+    _fields_ = [
+        ("max_iterations", C.c_int),
+        ("ransac_iterations", C.c_int),
+        ("transformation_epsilon", C.c_double),
+        ("euclidean_fitness_epsilon", C.c_double),
+        ("max_correspondence_distance", C.c_double),
+        ("ransac_outlier_threshold", C.c_double),
+        ("min_correspondences", C.c_int),
+    ]
+
+
+class IcpStats(C.Structure):
+    _fields_ = [
+        ("iterations", C.c_int),
+        ("converged", C.c_int),
+        ("last_correspondences", C.c_int),
+        ("last_inliers", C.c_int),
+        ("fitness_delta", C.c_double),
+        ("transform_delta", C.c_double),
+    ]
+
+
+# name -> (restype, argtypes); also the list the export test checks against include/pclmi.h
+SIGNATURES = {
+    "pclmi_version": (C.c_char_p, []),
+    "pclmi_last_error": (C.c_char_p, []),
+    "pclmi_device_count": (C.c_int, []),
+    "pclmi_set_device": (C.c_int, [C.c_int]),
+    "pclmi_tree_create": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int,
+                                    C.POINTER(C.c_void_p)]),
+    "pclmi_tree_destroy": (None, [C.c_void_p]),
+    "pclmi_tree_size": (C.c_size_t, [C.c_void_p]),
+    "pclmi_knn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p,
+                            C.POINTER(C.c_int)]),
+    "pclmi_knn_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p,
+                                C.c_void_p]),
+    "pclmi_radius": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_double, C.c_uint32, C.c_int,
+                               C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "pclmi_radius_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_double, C.c_uint32, C.c_int,
+                                   C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), c_u64p, C.c_void_p]),
+    "pclmi_free": (None, [C.c_void_p]),
+    "pclmi_free_dev": (None, [C.c_void_p]),
+    "pclmi_correspondences": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
+                                        C.c_double, C.c_void_p, C.POINTER(C.c_size_t)]),
+    "pclmi_correspondences_reciprocal": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t,
+                                                   C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t,
+                                                   C.c_double, C.c_void_p, C.POINTER(C.c_size_t)]),
+    "pclmi_estimate_rigid_svd": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
+                                           C.c_size_t, C.c_void_p, C.c_size_t, c_f32p]),
+    "pclmi_transform": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, c_f32p]),
+    "pclmi_icp_default_params": (None, [C.POINTER(IcpParams)]),
+    "pclmi_icp_align": (C.c_int, [C.POINTER(IcpParams), C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, c_f32p,
+                                  c_f32p, C.c_void_p, C.POINTER(IcpStats)]),
+    "pclmi_fitness_score": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, c_f32p, C.c_double, c_f64p]),
+    "pclmi_icp_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, c_f32p, C.POINTER(C.c_void_p)]),
+    "pclmi_icp_step_dev": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]),
+    "pclmi_icp_step": (C.c_int, [C.c_void_p, C.c_double, c_f64p]),
+    "pclmi_icp_solve": (C.c_int, [c_f64p, c_f32p]),
+    "pclmi_icp_set_transform": (C.c_int, [C.c_void_p, c_f32p]),
+    "pclmi_icp_end": (C.c_int, [C.c_void_p, C.c_void_p]),
+}
+
+
+def load_library(path=None):
+    """Loads libpclmi.so; raises if it has not been built (no fallback of any kind)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    p = Path(path) if path else LIB_PATH
+    if not p.exists():
+        raise PclmiError(2, "%s is missing - run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "or `make -C pcl_amd/csrc`" % p)
+    lib = C.CDLL(str(p))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise PclmiError(rc, load_library().pclmi_last_error().decode())
+
+
+def _pts(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if a.ndim != 2 or a.shape[1] not in (3, 4):
+        raise ValueError("points must be (n, 3) or (n, 4) float32, got %r" % (a.shape,))
+    return a
+
+
+def device_count():
+    return load_library().pclmi_device_count()
+
+
+class Tree:
+    """pcl::KdTreeFLANN::setInputCloud -> pclmi_tree_create."""
+
+    def __init__(self, cloud, indices=None):
+        lib = load_library()
+        self.cloud = _pts(cloud)
+        idx = None if indices is None else np.ascontiguousarray(indices, np.int32)
+        h = C.c_void_p()
+        _check(lib.pclmi_tree_create(self.cloud.ctypes.data, len(self.cloud), self.cloud.strides[0],
+                                     None if idx is None else idx.ctypes.data, 0 if idx is None else len(idx), 0,
+                                     C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            load_library().pclmi_tree_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return load_library().pclmi_tree_size(self.h)
+
+    def knn(self, queries, k):
+        """Host buffers in / out.  Returns (idx[nq, k_eff], d2[nq, k_eff])."""
+        q = _pts(queries)
+        ke = min(k, len(self))
+        idx = np.empty((len(q), ke), np.int32)
+        d2 = np.empty((len(q), ke), np.float32)
+        keff = C.c_int(0)
+        _check(load_library().pclmi_knn(self.h, q.ctypes.data, len(q), q.strides[0], k, idx.ctypes.data,
+                                        d2.ctypes.data, C.byref(keff)))
+        assert keff.value == ke
+        return idx, d2
+
+    def knn_dev(self, q_ptr, nq, q_stride_bytes, k, idx_ptr, d2_ptr, stream=None):
+        """Device pointers (ints) in / out; row pitch of the outputs is min(k, len(tree))."""
+        _check(load_library().pclmi_knn_dev(self.h, q_ptr, nq, q_stride_bytes, k, idx_ptr, d2_ptr, stream))
+
+    def radius(self, queries, radius, max_nn=0, sorted_results=True):
+        """Returns CSR (offsets[nq+1], idx, d2) as numpy arrays."""
+        lib = load_library()
+        q = _pts(queries)
+        offsets = np.zeros(len(q) + 1, np.uint64)
+        pi, pd = C.c_void_p(), C.c_void_p()
+        _check(lib.pclmi_radius(self.h, q.ctypes.data, len(q), q.strides[0], float(radius), max_nn,
+                                int(sorted_results), offsets.ctypes.data, C.byref(pi), C.byref(pd)))
+        total = int(offsets[-1])
+        if total:
+            idx = np.ctypeslib.as_array(C.cast(pi, c_i32p), shape=(total,)).copy()
+            d2 = np.ctypeslib.as_array(C.cast(pd, c_f32p), shape=(total,)).copy()
+        else:
+            idx, d2 = np.empty(0, np.int32), np.empty(0, np.float32)
+        lib.pclmi_free(pi)
+        lib.pclmi_free(pd)
+        return offsets.astype(np.int64), idx, d2
+
+
+def correspondences(target_tree, src, max_distance=float(np.sqrt(np.finfo(np.float64).max)), src_indices=None):
+    lib = load_library()
+    s = _pts(src)
+    si = None if src_indices is None else np.ascontiguousarray(src_indices, np.int32)
+    cap = len(s) if si is None else len(si)
+    out = np.zeros(cap, CORR_DTYPE)
+    n = C.c_size_t(0)
+    _check(lib.pclmi_correspondences(target_tree.h, s.ctypes.data, len(s), s.strides[0],
+                                     None if si is None else si.ctypes.data, 0 if si is None else len(si),
+                                     max_distance, out.ctypes.data, C.byref(n)))
+    return out[: n.value].copy()
+
+
+def correspondences_reciprocal(target_tree, source_tree, src, tgt,
+                               max_distance=float(np.sqrt(np.finfo(np.float64).max)), src_indices=None):
+    lib = load_library()
+    s, t = _pts(src), _pts(tgt)
+    si = None if src_indices is None else np.ascontiguousarray(src_indices, np.int32)
+    cap = len(s) if si is None else len(si)
+    out = np.zeros(cap, CORR_DTYPE)
+    n = C.c_size_t(0)
+    _check(lib.pclmi_correspondences_reciprocal(target_tree.h, source_tree.h, s.ctypes.data, len(s), s.strides[0],
+                                                None if si is None else si.ctypes.data,
+                                                0 if si is None else len(si), t.ctypes.data, len(t), t.strides[0],
+                                                max_distance, out.ctypes.data, C.byref(n)))
+    return out[: n.value].copy()
+
+
+def estimate_rigid_svd(src, tgt, src_idx=None, tgt_idx=None):
+    lib = load_library()
+    s, t = _pts(src), _pts(tgt)
+    si = None if src_idx is None else np.ascontiguousarray(src_idx, np.int32)
+    ti = None if tgt_idx is None else np.ascontiguousarray(tgt_idx, np.int32)
+    n = len(si) if si is not None else (len(ti) if ti is not None else len(s))
+    T = np.zeros(16, np.float32)
+    _check(lib.pclmi_estimate_rigid_svd(s.ctypes.data, len(s), s.strides[0], None if si is None else si.ctypes.data,
+                                        t.ctypes.data, len(t), t.strides[0], None if ti is None else ti.ctypes.data,
+                                        n, T.ctypes.data_as(c_f32p)))
+    return T.reshape(4, 4)
+
+
+def transform(points, T):
+    out = _pts(points).copy()
+    Tm = np.ascontiguousarray(T, np.float32).reshape(16)
+    _check(load_library().pclmi_transform(out.ctypes.data, len(out), out.strides[0], Tm.ctypes.data_as(c_f32p)))
+    return out
+
+
+def icp_default_params():
+    p = IcpParams()
+    load_library().pclmi_icp_default_params(C.byref(p))
+    return p
+
+
+def icp_align(target_tree, src, params=None, guess=None):
+    """pcl::IterativeClosestPoint::align.  Returns (status, T[4,4], aligned[n,4], stats)."""
+    lib = load_library()
+    s = _pts(src)
+    p = params or icp_default_params()
+    T = np.zeros(16, np.float32)
+    out = np.zeros((len(s), 4), np.float32)
+    st = IcpStats()
+    g = None if guess is None else np.ascontiguousarray(guess, np.float32).reshape(16)
+    rc = lib.pclmi_icp_align(C.byref(p), target_tree.h, s.ctypes.data, len(s), s.strides[0],
+                             None if g is None else g.ctypes.data_as(c_f32p), T.ctypes.data_as(c_f32p),
+                             out.ctypes.data, C.byref(st))
+    if rc not in (0, 6):
+        _check(rc)
+    return rc, T.reshape(4, 4), out, st
+
+
+def fitness_score(target_tree, src, T, max_range=float(np.finfo(np.float64).max)):
+    s = _pts(src)
+    Tm = np.ascontiguousarray(T, np.float32).reshape(16)
+    score = C.c_double(0)
+    _check(load_library().pclmi_fitness_score(target_tree.h, s.ctypes.data, len(s), s.strides[0],
+                                              Tm.ctypes.data_as(c_f32p), max_range, C.byref(score)))
+    return score.value
+
+
+def icp_solve(sums):
+    """Host-only: 24 fp64 sums -> row-major 4x4 (pclmi_icp_solve).  Needs no GPU."""
+    s = np.ascontiguousarray(sums, np.float64)
+    assert s.shape == (ICP_NSUMS,)
+    T = np.zeros(16, np.float32)
+    _check(load_library().pclmi_icp_solve(s.ctypes.data_as(c_f64p), T.ctypes.data_as(c_f32p)))
+    return T.reshape(4, 4)
+
+
+class IcpShard:
+    """Per-rank ICP context for the sharded driver (pclmi_icp_begin / step / set_transform / end)."""
+
+    def __init__(self, target_tree, src, guess=None):
+        lib = load_library()
+        self.src = _pts(src)
+        g = None if guess is None else np.ascontiguousarray(guess, np.float32).reshape(16)
+        h = C.c_void_p()
+        _check(lib.pclmi_icp_begin(target_tree.h, self.src.ctypes.data, len(self.src), self.src.strides[0],
+                                   None if g is None else g.ctypes.data_as(c_f32p), C.byref(h)))
+        self.h = h
+        self.n = len(self.src)
+
+    def step(self, max_correspondence_distance):
+        sums = np.zeros(ICP_NSUMS, np.float64)
+        _check(load_library().pclmi_icp_step(self.h, max_correspondence_distance, sums.ctypes.data_as(c_f64p)))
+        return sums
+
+    def step_dev(self, max_correspondence_distance, sums_ptr, stream=None):
+        _check(load_library().pclmi_icp_step_dev(self.h, max_correspondence_distance, sums_ptr, stream))
+
+    def set_transform(self, T):
+        Tm = np.ascontiguousarray(T, np.float32).reshape(16)
+        _check(load_library().pclmi_icp_set_transform(self.h, Tm.ctypes.data_as(c_f32p)))
+
+    def end(self, want_aligned=True):
+        out = np.zeros((self.n, 4), np.float32) if want_aligned else None
+        h, self.h = self.h, None
+        _check(load_library().pclmi_icp_end(h, None if out is None else out.ctypes.data))
+        return out
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            try:
+                load_library().pclmi_icp_end(self.h, None)
+            except Exception:
+                pass
+            self.h = None

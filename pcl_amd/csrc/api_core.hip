@@ -1,0 +1,272 @@
+// api_core.hip - C ABI: library/device management, tree lifetime, kNN entry points.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <new>
+
+#include <hipcub/hipcub.hpp>
+
+#include "pclmi_internal.h"
+
+namespace pclmi {
+
+static thread_local char g_err[512] = "";
+static thread_local int g_device = 0;
+
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char *what, const char *file, int line) {
+  set_error("HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
+  if (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver)
+    return PCLMI_ERR_NO_DEVICE;
+  if (e == hipErrorOutOfMemory) return PCLMI_ERR_OOM;
+  return PCLMI_ERR_HIP;
+}
+
+int Workspace::ensure_queries(size_t nq) {
+  if (nq <= cap_q) return PCLMI_OK;
+  size_t cap = nq + nq / 8 + 1024;
+  if (keys_in) (void)hipFree(keys_in);
+  if (keys_out) (void)hipFree(keys_out);
+  if (vals_in) (void)hipFree(vals_in);
+  if (vals_out) (void)hipFree(vals_out);
+  if (sort_tmp) (void)hipFree(sort_tmp);
+  keys_in = keys_out = nullptr;
+  vals_in = vals_out = nullptr;
+  sort_tmp = nullptr;
+  cap_q = 0;
+  PCLMI_HIP(hipMalloc(&keys_in, cap * 4));
+  PCLMI_HIP(hipMalloc(&keys_out, cap * 4));
+  PCLMI_HIP(hipMalloc(&vals_in, cap * 4));
+  PCLMI_HIP(hipMalloc(&vals_out, cap * 4));
+  size_t tmp = 0;
+  PCLMI_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, keys_in, keys_out, vals_in, vals_out, (int)cap, 0, 30,
+                                               (hipStream_t) nullptr));
+  cap_tmp = tmp + 256;
+  PCLMI_HIP(hipMalloc(&sort_tmp, cap_tmp));
+  cap_q = cap;
+  return PCLMI_OK;
+}
+
+int Workspace::ensure_scratch(size_t bytes) {
+  if (bytes <= cap_scratch) return PCLMI_OK;
+  if (scratch) (void)hipFree(scratch);
+  scratch = nullptr;
+  cap_scratch = 0;
+  size_t cap = bytes + bytes / 8 + 4096;
+  PCLMI_HIP(hipMalloc(&scratch, cap));
+  cap_scratch = cap;
+  return PCLMI_OK;
+}
+
+void Workspace::release() {
+  if (keys_in) (void)hipFree(keys_in);
+  if (keys_out) (void)hipFree(keys_out);
+  if (vals_in) (void)hipFree(vals_in);
+  if (vals_out) (void)hipFree(vals_out);
+  if (sort_tmp) (void)hipFree(sort_tmp);
+  if (scratch) (void)hipFree(scratch);
+  *this = Workspace();
+}
+
+Workspace *acquire_ws(const pclmi_tree *t) {
+  std::lock_guard<std::mutex> g(t->mu);
+  if (!t->pool.empty()) {
+    Workspace *w = t->pool.back();
+    t->pool.pop_back();
+    return w;
+  }
+  return new Workspace();
+}
+
+void release_ws(const pclmi_tree *t, Workspace *w) {
+  std::lock_guard<std::mutex> g(t->mu);
+  t->pool.push_back(w);
+}
+
+}  // namespace pclmi
+
+using namespace pclmi;
+
+extern "C" {
+
+const char *pclmi_version(void) { return "pclmi 0.1 (gfx950)"; }
+const char *pclmi_last_error(void) { return g_err; }
+
+int pclmi_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int pclmi_set_device(int device) {
+  int n = pclmi_device_count();
+  PCLMI_CHECK(n > 0, PCLMI_ERR_NO_DEVICE, "no HIP device visible");
+  PCLMI_CHECK(device >= 0 && device < n, PCLMI_ERR_INVALID, "device %d out of range (0..%d)", device, n - 1);
+  PCLMI_HIP(hipSetDevice(device));
+  g_device = device;
+  return PCLMI_OK;
+}
+
+int pclmi_tree_create(const float *xyz, size_t n, size_t stride_bytes, const int32_t *indices, size_t n_indices,
+                      int leaf_max, pclmi_tree **out) {
+  (void)leaf_max;  // bucket size is a compile-time constant of the kernels (kLeafSize)
+  PCLMI_CHECK(out != nullptr, PCLMI_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  PCLMI_CHECK(n == 0 || xyz != nullptr, PCLMI_ERR_INVALID, "xyz is NULL");
+  PCLMI_CHECK(stride_bytes >= 12 && stride_bytes % 4 == 0, PCLMI_ERR_INVALID,
+              "stride_bytes must be a multiple of 4 and >= 12 (got %zu)", stride_bytes);
+  PCLMI_CHECK(n < ((size_t)1 << 31), PCLMI_ERR_UNSUPPORTED, "cloud has more than 2^31-1 rows");
+  PCLMI_CHECK(pclmi_device_count() > 0, PCLMI_ERR_NO_DEVICE,
+              "no HIP device visible: libpclmi has no CPU fallback");
+  PCLMI_HIP(hipSetDevice(g_device));
+  const size_t sf = stride_bytes / 4;
+  // convertCloudToArray (impl/kdtree_flann.hpp:180-249): keep finite rows, remember their index
+  std::vector<float> pts;
+  std::vector<int32_t> ext;
+  const size_t cand = indices ? n_indices : n;
+  pts.reserve(cand * 3);
+  ext.reserve(cand);
+  for (size_t a = 0; a < cand; ++a) {
+    size_t row = indices ? (size_t)indices[a] : a;
+    PCLMI_CHECK(row < n, PCLMI_ERR_INVALID, "indices[%zu] = %zu is outside the cloud (%zu rows)", a, row, n);
+    const float *p = xyz + row * sf;
+    if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2])) continue;
+    pts.push_back(p[0]);
+    pts.push_back(p[1]);
+    pts.push_back(p[2]);
+    ext.push_back((int32_t)row);
+  }
+  pclmi_tree *t = new (std::nothrow) pclmi_tree();
+  PCLMI_CHECK(t != nullptr, PCLMI_ERR_OOM, "out of host memory");
+  t->device = g_device;
+  t->n = ext.size();
+  t->rows = n;
+  int rc = PCLMI_OK;
+  auto fail = [&](int code) {
+    pclmi_tree_destroy(t);
+    return code;
+  };
+  if (hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking) != hipSuccess)
+    return fail(hip_fail(hipGetLastError(), "hipStreamCreate", __FILE__, __LINE__));
+  if (t->n > 0) {
+    HostTree ht;
+    build_host_tree(pts.data(), ext.data(), t->n, &ht);
+    t->M = ht.M;
+    for (int d = 0; d < 3; ++d) {
+      t->bb_lo[d] = ht.bb_lo[d];
+      t->bb_hi[d] = ht.bb_hi[d];
+    }
+    hipError_t e;
+    if ((e = hipMalloc(&t->d_box, ht.box.size() * 4)) != hipSuccess ||
+        (e = hipMalloc(&t->d_leaf, ht.leaf.size() * 4)) != hipSuccess ||
+        (e = hipMemcpy(t->d_box, ht.box.data(), ht.box.size() * 4, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(t->d_leaf, ht.leaf.data(), ht.leaf.size() * 4, hipMemcpyHostToDevice)) != hipSuccess)
+      return fail(hip_fail(e, "tree upload", __FILE__, __LINE__));
+  }
+  if (n > 0) {
+    // original rows as (x, y, z, 1): target_ of Registration::setInputTarget (registration.hpp:49-55)
+    std::vector<float> cloud(n * 4);
+    for (size_t i = 0; i < n; ++i) {
+      const float *p = xyz + i * sf;
+      cloud[i * 4 + 0] = p[0];
+      cloud[i * 4 + 1] = p[1];
+      cloud[i * 4 + 2] = p[2];
+      cloud[i * 4 + 3] = 1.f;
+    }
+    hipError_t e;
+    if ((e = hipMalloc(&t->d_cloud, n * 16)) != hipSuccess ||
+        (e = hipMemcpy(t->d_cloud, cloud.data(), n * 16, hipMemcpyHostToDevice)) != hipSuccess)
+      return fail(hip_fail(e, "cloud upload", __FILE__, __LINE__));
+  }
+  (void)rc;
+  *out = t;
+  return PCLMI_OK;
+}
+
+void pclmi_tree_destroy(pclmi_tree *t) {
+  if (!t) return;
+  (void)hipSetDevice(t->device);
+  for (Workspace *w : t->pool) {
+    w->release();
+    delete w;
+  }
+  t->pool.clear();
+  if (t->d_box) (void)hipFree(t->d_box);
+  if (t->d_leaf) (void)hipFree(t->d_leaf);
+  if (t->d_cloud) (void)hipFree(t->d_cloud);
+  if (t->stream) (void)hipStreamDestroy(t->stream);
+  delete t;
+}
+
+size_t pclmi_tree_size(const pclmi_tree *t) { return t ? t->n : 0; }
+
+int pclmi_knn_dev(const pclmi_tree *t, const float *d_q, size_t nq, size_t q_stride_bytes, int k, int32_t *d_idx,
+                  float *d_d2, void *stream) {
+  PCLMI_CHECK(t != nullptr, PCLMI_ERR_INVALID, "tree is NULL");
+  PCLMI_CHECK(k > 0, PCLMI_ERR_INVALID, "k must be positive (got %d)", k);
+  PCLMI_CHECK(q_stride_bytes >= 12 && q_stride_bytes % 4 == 0, PCLMI_ERR_INVALID, "bad query stride %zu",
+              q_stride_bytes);
+  const int k_eff = (size_t)k > t->n ? (int)t->n : k;  // impl/kdtree_flann.hpp:85-86
+  if (nq == 0 || k_eff == 0) return PCLMI_OK;
+  PCLMI_CHECK(d_q && d_idx && d_d2, PCLMI_ERR_INVALID, "NULL query/output pointer");
+  PCLMI_HIP(hipSetDevice(t->device));
+  hipStream_t s = stream ? (hipStream_t)stream : t->stream;
+  WsGuard g(t);
+  const int32_t *order = nullptr;
+  int rc = launch_morton_order(t, g.w, d_q, nq, q_stride_bytes / 4, s, &order);
+  if (rc) return rc;
+  rc = launch_knn(t, g.w, d_q, nq, q_stride_bytes / 4, order, k_eff, d_idx, d_d2, s);
+  if (rc) return rc;
+  // the workspace goes back to the pool when this returns: wait for the kernels using it
+  PCLMI_HIP(hipStreamSynchronize(s));
+  return PCLMI_OK;
+}
+
+int pclmi_knn(const pclmi_tree *t, const float *q, size_t nq, size_t q_stride_bytes, int k, int32_t *idx,
+              float *d2, int *k_eff_out) {
+  PCLMI_CHECK(t != nullptr, PCLMI_ERR_INVALID, "tree is NULL");
+  PCLMI_CHECK(k > 0, PCLMI_ERR_INVALID, "k must be positive (got %d)", k);
+  PCLMI_CHECK(q_stride_bytes >= 12 && q_stride_bytes % 4 == 0, PCLMI_ERR_INVALID, "bad query stride %zu",
+              q_stride_bytes);
+  const int k_eff = (size_t)k > t->n ? (int)t->n : k;
+  if (k_eff_out) *k_eff_out = k_eff;
+  if (nq == 0 || k_eff == 0) return PCLMI_OK;
+  PCLMI_CHECK(q && idx && d2, PCLMI_ERR_INVALID, "NULL query/output pointer");
+  PCLMI_HIP(hipSetDevice(t->device));
+  float *d_q = nullptr;
+  int32_t *d_idx = nullptr;
+  float *d_d2 = nullptr;
+  const size_t out_n = nq * (size_t)k_eff;
+  int rc = PCLMI_OK;
+  hipError_t e;
+  if ((e = hipMalloc(&d_q, nq * q_stride_bytes)) != hipSuccess ||
+      (e = hipMalloc(&d_idx, out_n * 4)) != hipSuccess || (e = hipMalloc(&d_d2, out_n * 4)) != hipSuccess ||
+      (e = hipMemcpy(d_q, q, nq * q_stride_bytes, hipMemcpyHostToDevice)) != hipSuccess) {
+    rc = hip_fail(e, "query upload", __FILE__, __LINE__);
+  } else {
+    rc = pclmi_knn_dev(t, d_q, nq, q_stride_bytes, k, d_idx, d_d2, nullptr);
+    if (rc == PCLMI_OK) {
+      if ((e = hipMemcpy(idx, d_idx, out_n * 4, hipMemcpyDeviceToHost)) != hipSuccess ||
+          (e = hipMemcpy(d2, d_d2, out_n * 4, hipMemcpyDeviceToHost)) != hipSuccess)
+        rc = hip_fail(e, "result download", __FILE__, __LINE__);
+    }
+  }
+  if (d_q) (void)hipFree(d_q);
+  if (d_idx) (void)hipFree(d_idx);
+  if (d_d2) (void)hipFree(d_d2);
+  return rc;
+}
+
+void pclmi_free(void *p) { free(p); }
+void pclmi_free_dev(void *p) {
+  if (p) (void)hipFree(p);
+}
+
+}  // extern "C"

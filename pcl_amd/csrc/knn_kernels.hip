@@ -1,0 +1,522 @@
+// knn_kernels.hip - exact k-nearest-neighbour search on gfx950 (MI355X), wave64.
+//
+// Replaces the FLANN traversal behind pcl::KdTreeFLANN::nearestKSearch
+// (kdtree/include/pcl/kdtree/impl/kdtree_flann.hpp:97-99).
+//
+// Design (DESIGN.md "kNN kernel"): queries are Morton-sorted, so the 64 queries of a
+// wavefront are spatial neighbours.  A wavefront therefore walks the tree ONCE for all of its
+// lanes ("union traversal"): the node stack is wave-uniform (one VGPR used as a 64-entry lane
+// stack, read with v_readlane), node boxes and bucket points are fetched with SCALAR loads
+// (s_load_dwordx16 through the constant address space) and live in SGPRs, and every lane
+// tests every fetched point against its own query.  A node is visited iff ANY lane still needs
+// it (its box distance <= that lane's current k-th distance).  There is no divergent memory
+// access and no divergent control flow in the hot loop.
+//
+// k-best bookkeeping per lane:
+//   * a[K]   sorted list of the K smallest DISTANCES seen so far, kept in registers and updated
+//            with a branch-free v_med3_f32 chain: new a[j] = med3(a[j-1], a[j], d).
+//            a[K-1] is the exact running k-th distance (the pruning bound).
+//   * buf    per-lane append buffer in LDS holding (d2, index) of every candidate that was
+//            <= the bound when seen.  When a lane's buffer fills, the wave compacts it against
+//            the current bound.  At the end the buffer is filtered with the final bound and the
+//            <= K survivors are sorted by the 64-bit key (d2 bits << 32 | index) in registers.
+// This keeps the per-candidate cost at ~8 (distance) + K (med3) + ~5 (append) VALU instructions
+// and still yields the exact (d2, index) order including ties.
+#include <hipcub/hipcub.hpp>
+
+#include "pclmi_internal.h"
+
+namespace pclmi {
+namespace {
+
+// Uniform (scalar) loads: reading through the constant address space with a wave-uniform
+// address makes hipcc emit s_load_dwordx8 / x16 into SGPRs instead of per-lane vector loads.
+typedef float f8v __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef const f8v __attribute__((address_space(4))) *cbox_ptr;    // one node box (32 B)
+typedef const f16v __attribute__((address_space(4))) *cgrp_ptr;   // 64-byte line
+
+constexpr int L = kLeafSize;
+constexpr int G = L / 4;  // point groups per bucket: [x0..3 | y0..3 | z0..3 | idx0..3]
+
+__device__ __forceinline__ float sq3(float dx, float dy, float dz) {
+  // one rounding per operation, fixed order: ((dx*dx + dy*dy) + dz*dz)
+  return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+// squared distance from q to an axis-aligned box given as 8 uniform floats.  Uses the same
+// operation order as sq3, so it is a true lower bound (in fp32) of sq3 to any point inside.
+__device__ __forceinline__ float box_dist(float qx, float qy, float qz, float lx, float ly, float lz,
+                                          float hx, float hy, float hz) {
+  float dx = fmaxf(fmaxf(lx - qx, qx - hx), 0.f);
+  float dy = fmaxf(fmaxf(ly - qy, qy - hy), 0.f);
+  float dz = fmaxf(fmaxf(lz - qz, qz - hz), 0.f);
+  return sq3(dx, dy, dz);
+}
+
+__device__ __forceinline__ unsigned long long make_key(float d, int i) {
+  return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)i;
+}
+
+template <int K>
+__device__ __forceinline__ void list_insert(float (&a)[K], float d) {
+  // a ascending.  new a[j] = median(a[j-1], a[j], d); new a[0] = min(a[0], d).
+#pragma unroll
+  for (int j = K - 1; j >= 1; --j) a[j] = __builtin_amdgcn_fmed3f(a[j - 1], a[j], d);
+  a[0] = fminf(a[0], d);
+}
+
+// wave-uniform stack kept in the lanes of one VGPR
+struct LaneStack {
+  int v;
+  int sp;
+  int lane;
+  __device__ __forceinline__ void push(int node) {
+    v = (lane == sp) ? node : v;
+    ++sp;
+  }
+  __device__ __forceinline__ int pop() {
+    --sp;
+    return __builtin_amdgcn_readlane(v, sp);
+  }
+};
+
+// Compacts a lane's append buffer against bound `tau`: keeps entries with d <= tau (in place).
+// If more than K survive (distance ties at the bound) the largest-index ties are dropped until
+// exactly K remain - entries outside the current K best can never enter the final result.
+template <int K, int C>
+__device__ __forceinline__ int compact_buffer(uint2 (*buf)[64], int lane, int cnt, float tau) {
+  int maxcnt = cnt;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) maxcnt = max(maxcnt, __shfl_xor(maxcnt, o));
+  int n = 0;
+  for (int e = 0; e < maxcnt; ++e) {
+    if (e < cnt) {
+      uint2 v = buf[e][lane];
+      if (__uint_as_float(v.x) <= tau) {
+        buf[n][lane] = v;
+        ++n;
+      }
+    }
+  }
+  // rare: ties at the bound
+  while (n > K) {
+    int worst = -1;
+    unsigned int worst_idx = 0;
+    for (int e = 0; e < n; ++e) {
+      uint2 v = buf[e][lane];
+      if (__uint_as_float(v.x) == tau && (worst < 0 || v.y > worst_idx)) {
+        worst = e;
+        worst_idx = v.y;
+      }
+    }
+    buf[worst][lane] = buf[n - 1][lane];
+    --n;
+  }
+  return n;
+}
+
+template <int N>
+__device__ __forceinline__ void sort_keys(unsigned long long (&k)[N]) {
+  // bitonic sorting network on N (power of two) 64-bit keys held in registers
+#pragma unroll
+  for (int size = 2; size <= N; size <<= 1) {
+#pragma unroll
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        int j = i ^ stride;
+        if (j > i) {
+          bool up = (i & size) == 0;
+          unsigned long long x = k[i], y = k[j];
+          bool sw = up ? (y < x) : (x < y);
+          k[i] = sw ? y : x;
+          k[j] = sw ? x : y;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K >= 2 : register distance list + LDS append buffer.  WPB waves per block, C buffer entries.
+template <int K, int C, int WPB>
+__global__ __launch_bounds__(64 * WPB) void knn_union_kernel(TreeView t, const float *__restrict__ q,
+                                                              int q_stride_f,
+                                                              const int *__restrict__ order, int nq,
+                                                              int k_out, int *__restrict__ out_idx,
+                                                              float *__restrict__ out_d2) {
+  static_assert(C >= K + L, "buffer must hold the K best plus one bucket");
+  __shared__ uint2 lds[WPB][C][64];
+  const int lane = threadIdx.x & 63;
+  const int wib = threadIdx.x >> 6;
+  // XCD-aware chunk assignment: blocks b, b+8, b+16 ... share an XCD (and its L2); give each
+  // XCD one contiguous range of the sorted queries so that its L2 holds one part of the tree.
+  const int nblk = gridDim.x;
+  const int per = (nblk + 7) >> 3;
+  const int blk = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  const int slot = (blk * WPB + wib) * 64 + lane;
+  if (__builtin_amdgcn_readfirstlane(slot) >= nq) return;  // whole wave past the end
+  const bool alive = slot < nq;
+  const int qi = alive ? (order ? order[slot] : slot) : 0;
+  float qx = __builtin_nanf(""), qy = qx, qz = qx;
+  if (alive) {
+    const float *p = q + (size_t)qi * q_stride_f;
+    qx = p[0];
+    qy = p[1];
+    qz = p[2];
+  }
+  uint2(*buf)[64] = lds[wib];
+
+  float a[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) a[j] = 3.402823466e+38f;  // FLT_MAX: padded slots (d2=+inf) never pass
+  int cnt = 0;
+
+  LaneStack st{0, 0, lane};
+  st.push(1);
+  const cbox_ptr box = (cbox_ptr)t.box;
+  const cgrp_ptr box2 = (cgrp_ptr)t.box;
+  const cgrp_ptr leaf = (cgrp_ptr)t.leaf;
+  const int M = t.M;
+
+  while (st.sp > 0) {
+    const int node = st.pop();
+    if (node >= M) {
+      // ---- bucket: re-test its box against the (possibly tighter) bound, then scan it
+      const f8v b = box[node];
+      const cgrp_ptr rec = leaf + (size_t)(node - M) * G;
+      f16v grp[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) grp[g] = rec[g];
+      const float md = box_dist(qx, qy, qz, b[0], b[1], b[2], b[3], b[4], b[5]);
+      if (!__any(md <= a[K - 1])) continue;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float d = sq3(qx - grp[g][j], qy - grp[g][4 + j], qz - grp[g][8 + j]);
+          if (d <= a[K - 1]) {
+            buf[cnt][lane] = make_uint2(__float_as_uint(d), __float_as_uint(grp[g][12 + j]));
+            ++cnt;
+          }
+          list_insert<K>(a, d);
+        }
+      }
+      if (__any(cnt > C - L)) cnt = compact_buffer<K, C>(buf, lane, cnt, a[K - 1]);
+    } else {
+      // ---- inner node: both children's boxes are one 64-byte line
+      const f16v b = box2[node];
+      const float m0 = box_dist(qx, qy, qz, b[0], b[1], b[2], b[3], b[4], b[5]);
+      const float m1 = box_dist(qx, qy, qz, b[8], b[9], b[10], b[11], b[12], b[13]);
+      const float tau = a[K - 1];
+      const bool n0 = __any(m0 <= tau), n1 = __any(m1 <= tau);
+      // nearer child (by lane majority) is pushed last, i.e. visited first
+      const bool first0 = __popcll(__ballot(m0 <= m1)) >= 32;
+      const int c0 = 2 * node, c1 = 2 * node + 1;
+      if (first0) {
+        if (n1) st.push(c1);
+        if (n0) st.push(c0);
+      } else {
+        if (n0) st.push(c0);
+        if (n1) st.push(c1);
+      }
+    }
+  }
+
+  // ---- final: filter with the exact k-th distance, sort the survivors by (d2, index)
+  cnt = compact_buffer<K, C>(buf, lane, cnt, a[K - 1]);
+  unsigned long long key[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    uint2 v = buf[j][lane];  // C >= K, always in bounds; masked by cnt
+    key[j] = j < cnt ? (((unsigned long long)v.x << 32) | v.y) : ~0ull;
+  }
+  sort_keys<K>(key);
+  if (alive) {
+    int *oi = out_idx + (size_t)qi * k_out;
+    float *od = out_d2 + (size_t)qi * k_out;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      if (j < k_out) {
+        oi[j] = (int)(unsigned int)(key[j] & 0xffffffffull);
+        od[j] = __uint_as_float((unsigned int)(key[j] >> 32));
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K == 1 : running best 64-bit key, no buffer.
+template <int WPB>
+__global__ __launch_bounds__(64 * WPB) void knn1_union_kernel(TreeView t, const float *__restrict__ q,
+                                                               int q_stride_f,
+                                                               const int *__restrict__ order, int nq,
+                                                               int *__restrict__ out_idx,
+                                                               float *__restrict__ out_d2) {
+  const int lane = threadIdx.x & 63;
+  const int wib = threadIdx.x >> 6;
+  const int nblk = gridDim.x;
+  const int per = (nblk + 7) >> 3;
+  const int blk = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  const int slot = (blk * WPB + wib) * 64 + lane;
+  if (__builtin_amdgcn_readfirstlane(slot) >= nq) return;
+  const bool alive = slot < nq;
+  const int qi = alive ? (order ? order[slot] : slot) : 0;
+  float qx = __builtin_nanf(""), qy = qx, qz = qx;
+  if (alive) {
+    const float *p = q + (size_t)qi * q_stride_f;
+    qx = p[0];
+    qy = p[1];
+    qz = p[2];
+  }
+  unsigned long long best = make_key(3.402823466e+38f, 0x7fffffff);
+  float tau = 3.402823466e+38f;
+  LaneStack st{0, 0, lane};
+  st.push(1);
+  const cbox_ptr box = (cbox_ptr)t.box;
+  const cgrp_ptr box2 = (cgrp_ptr)t.box;
+  const cgrp_ptr leaf = (cgrp_ptr)t.leaf;
+  const int M = t.M;
+  while (st.sp > 0) {
+    const int node = st.pop();
+    if (node >= M) {
+      const f8v b = box[node];
+      const cgrp_ptr rec = leaf + (size_t)(node - M) * G;
+      f16v grp[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) grp[g] = rec[g];
+      if (!__any(box_dist(qx, qy, qz, b[0], b[1], b[2], b[3], b[4], b[5]) <= tau)) continue;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float d = sq3(qx - grp[g][j], qy - grp[g][4 + j], qz - grp[g][8 + j]);
+          const unsigned long long key = make_key(d, __float_as_int(grp[g][12 + j]));
+          best = key < best ? key : best;
+        }
+      }
+      tau = __uint_as_float((unsigned int)(best >> 32));
+    } else {
+      const f16v b = box2[node];
+      const float m0 = box_dist(qx, qy, qz, b[0], b[1], b[2], b[3], b[4], b[5]);
+      const float m1 = box_dist(qx, qy, qz, b[8], b[9], b[10], b[11], b[12], b[13]);
+      const bool n0 = __any(m0 <= tau), n1 = __any(m1 <= tau);
+      const bool first0 = __popcll(__ballot(m0 <= m1)) >= 32;
+      const int c0 = 2 * node, c1 = 2 * node + 1;
+      if (first0) {
+        if (n1) st.push(c1);
+        if (n0) st.push(c0);
+      } else {
+        if (n0) st.push(c0);
+        if (n1) st.push(c1);
+      }
+    }
+  }
+  if (alive) {
+    out_idx[qi] = (int)(unsigned int)(best & 0xffffffffull);
+    out_d2[qi] = __uint_as_float((unsigned int)(best >> 32));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Any k: one query per lane, private traversal, (d2,index) max-heap in global scratch laid out
+// [k][nq] so that neighbouring lanes touch neighbouring words.  Slow path for k > 32.
+__global__ __launch_bounds__(64) void knn_heap_kernel(TreeView t, const float *__restrict__ q,
+                                                      int q_stride_f, const int *__restrict__ order,
+                                                      int nq, int k, unsigned long long *heap,
+                                                      int *__restrict__ out_idx,
+                                                      float *__restrict__ out_d2) {
+  const int slot = blockIdx.x * 64 + threadIdx.x;
+  if (slot >= nq) return;
+  const int qi = order ? order[slot] : slot;
+  const float *p = q + (size_t)qi * q_stride_f;
+  const float qx = p[0], qy = p[1], qz = p[2];
+  unsigned long long *h = heap + slot;  // element e at h[e * nq]
+  const size_t S = (size_t)nq;
+  int cnt = 0;
+  int stack[64];
+  int sp = 0;
+  stack[sp++] = 1;
+  const int M = t.M;
+  while (sp > 0) {
+    const int node = stack[--sp];
+    const float *b = t.box + (size_t)node * 8;
+    float dx = fmaxf(fmaxf(b[0] - qx, qx - b[3]), 0.f);
+    float dy = fmaxf(fmaxf(b[1] - qy, qy - b[4]), 0.f);
+    float dz = fmaxf(fmaxf(b[2] - qz, qz - b[5]), 0.f);
+    const float md = sq3(dx, dy, dz);
+    if (cnt == k && md > __uint_as_float((unsigned int)(h[0] >> 32))) continue;
+    if (node >= M) {
+      const float *rec = t.leaf + (size_t)(node - M) * (4 * L);
+      for (int j = 0; j < L; ++j) {
+        const float *gp = rec + (j >> 2) * 16 + (j & 3);
+        const int idx = __float_as_int(gp[12]);
+        if (idx < 0) continue;  // padded slot
+        const float d = sq3(qx - gp[0], qy - gp[4], qz - gp[8]);
+        const unsigned long long key = make_key(d, idx);
+        if (cnt < k) {  // sift up
+          int c = cnt++;
+          while (c > 0) {
+            int par = (c - 1) >> 1;
+            unsigned long long pk = h[par * S];
+            if (pk >= key) break;
+            h[c * S] = pk;
+            c = par;
+          }
+          h[c * S] = key;
+        } else if (key < h[0]) {  // replace the maximum, sift down
+          int c = 0;
+          for (;;) {
+            int l = 2 * c + 1, r = l + 1;
+            if (l >= k) break;
+            unsigned long long lk = h[l * S];
+            int m = l;
+            unsigned long long mk = lk;
+            if (r < k) {
+              unsigned long long rk = h[r * S];
+              if (rk > lk) { m = r; mk = rk; }
+            }
+            if (mk <= key) break;
+            h[c * S] = mk;
+            c = m;
+          }
+          h[c * S] = key;
+        }
+      }
+    } else {
+      // visit the nearer child first
+      const float *b0 = t.box + (size_t)node * 16;
+      float ax = fmaxf(fmaxf(b0[0] - qx, qx - b0[3]), 0.f), ay = fmaxf(fmaxf(b0[1] - qy, qy - b0[4]), 0.f),
+            az = fmaxf(fmaxf(b0[2] - qz, qz - b0[5]), 0.f);
+      float bx = fmaxf(fmaxf(b0[8] - qx, qx - b0[11]), 0.f), by = fmaxf(fmaxf(b0[9] - qy, qy - b0[12]), 0.f),
+            bz = fmaxf(fmaxf(b0[10] - qz, qz - b0[13]), 0.f);
+      if (sq3(ax, ay, az) <= sq3(bx, by, bz)) {
+        stack[sp++] = 2 * node + 1;
+        stack[sp++] = 2 * node;
+      } else {
+        stack[sp++] = 2 * node;
+        stack[sp++] = 2 * node + 1;
+      }
+    }
+  }
+  // heap sort: repeatedly move the maximum to the end -> ascending order
+  for (int end = cnt - 1; end > 0; --end) {
+    unsigned long long top = h[0], key = h[end * S];
+    h[end * S] = top;
+    int c = 0;
+    for (;;) {
+      int l = 2 * c + 1, r = l + 1;
+      if (l >= end) break;
+      unsigned long long lk = h[l * S];
+      int m = l;
+      unsigned long long mk = lk;
+      if (r < end) {
+        unsigned long long rk = h[r * S];
+        if (rk > lk) { m = r; mk = rk; }
+      }
+      if (mk <= key) break;
+      h[c * S] = mk;
+      c = m;
+    }
+    h[c * S] = key;
+  }
+  int *oi = out_idx + (size_t)qi * k;
+  float *od = out_d2 + (size_t)qi * k;
+  for (int j = 0; j < k; ++j) {
+    unsigned long long key = j < cnt ? h[j * S] : ~0ull;
+    oi[j] = j < cnt ? (int)(unsigned int)(key & 0xffffffffull) : -1;
+    od[j] = j < cnt ? __uint_as_float((unsigned int)(key >> 32)) : __builtin_nanf("");
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Morton codes of the queries relative to the tree's bounding box (10 bits per axis).
+__device__ __forceinline__ unsigned int spread10(unsigned int v) {
+  v = (v | (v << 16)) & 0x030000FFu;
+  v = (v | (v << 8)) & 0x0300F00Fu;
+  v = (v | (v << 4)) & 0x030C30C3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+
+__global__ void morton_kernel(const float *__restrict__ q, int q_stride_f, int nq, float lox, float loy,
+                              float loz, float sx, float sy, float sz, unsigned int *__restrict__ keys,
+                              int *__restrict__ vals) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  const float *p = q + (size_t)i * q_stride_f;
+  float fx = (p[0] - lox) * sx, fy = (p[1] - loy) * sy, fz = (p[2] - loz) * sz;
+  // NaN / out-of-box queries clamp into the grid; order only affects speed, never results
+  unsigned int ix = (unsigned int)fminf(fmaxf(fx, 0.f), 1023.f);
+  unsigned int iy = (unsigned int)fminf(fmaxf(fy, 0.f), 1023.f);
+  unsigned int iz = (unsigned int)fminf(fmaxf(fz, 0.f), 1023.f);
+  keys[i] = spread10(ix) | (spread10(iy) << 1) | (spread10(iz) << 2);
+  vals[i] = i;
+}
+
+}  // namespace
+
+int launch_morton_order(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq,
+                        size_t q_stride_f, hipStream_t s, const int32_t **d_order) {
+  *d_order = nullptr;
+  if (nq <= 64) return PCLMI_OK;  // a single wave: order is irrelevant
+  int rc = w->ensure_queries(nq);
+  if (rc) return rc;
+  float sc[3];
+  for (int d = 0; d < 3; ++d) {
+    float ext = t->bb_hi[d] - t->bb_lo[d];
+    sc[d] = ext > 0.f ? 1024.f / ext : 0.f;
+  }
+  hipLaunchKernelGGL(morton_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, d_q,
+                     (int)q_stride_f, (int)nq, t->bb_lo[0], t->bb_lo[1], t->bb_lo[2], sc[0], sc[1], sc[2],
+                     w->keys_in, w->vals_in);
+  size_t tmp = w->cap_tmp;
+  PCLMI_HIP(hipcub::DeviceRadixSort::SortPairs(w->sort_tmp, tmp, w->keys_in, w->keys_out, w->vals_in,
+                                               w->vals_out, (int)nq, 0, 30, s));
+  *d_order = w->vals_out;
+  return PCLMI_OK;
+}
+
+template <int K, int C, int WPB>
+static void launch_union(const pclmi_tree *t, const float *d_q, size_t nq, size_t qsf, const int32_t *order,
+                         int k_eff, int32_t *d_idx, float *d_d2, hipStream_t s) {
+  unsigned waves = (unsigned)((nq + 63) / 64);
+  unsigned blocks = (waves + WPB - 1) / WPB;
+  blocks = (blocks + 7) & ~7u;  // the XCD remap assumes a multiple of 8
+  hipLaunchKernelGGL((knn_union_kernel<K, C, WPB>), dim3(blocks), dim3(64 * WPB), 0, s, t->view(), d_q,
+                     (int)qsf, order, (int)nq, k_eff, d_idx, d_d2);
+}
+
+int launch_knn(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, size_t qsf,
+               const int32_t *order, int k_eff, int32_t *d_idx, float *d_d2, hipStream_t s) {
+  if (nq == 0 || k_eff <= 0) return PCLMI_OK;
+  PCLMI_CHECK(nq < (size_t)1 << 31, PCLMI_ERR_UNSUPPORTED, "more than 2^31-1 queries in one call");
+  if (k_eff == 1) {
+    constexpr int WPB = 4;
+    unsigned waves = (unsigned)((nq + 63) / 64);
+    unsigned blocks = ((waves + WPB - 1) / WPB + 7) & ~7u;
+    hipLaunchKernelGGL((knn1_union_kernel<WPB>), dim3(blocks), dim3(64 * WPB), 0, s, t->view(), d_q, (int)qsf,
+                       order, (int)nq, d_idx, d_d2);
+  } else if (k_eff <= 2) {
+    launch_union<2, 24, 4>(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
+  } else if (k_eff <= 4) {
+    launch_union<4, 24, 4>(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
+  } else if (k_eff <= 8) {
+    launch_union<8, 32, 2>(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
+  } else if (k_eff <= 16) {
+    launch_union<16, 40, 2>(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
+  } else if (k_eff <= 32) {
+    launch_union<32, 64, 1>(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
+  } else {
+    size_t bytes = (size_t)k_eff * nq * sizeof(unsigned long long);
+    int rc = w->ensure_scratch(bytes);
+    if (rc) return rc;
+    hipLaunchKernelGGL(knn_heap_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, s, t->view(), d_q,
+                       (int)qsf, order, (int)nq, k_eff, (unsigned long long *)w->scratch, d_idx, d_d2);
+  }
+  PCLMI_HIP(hipGetLastError());
+  return PCLMI_OK;
+}
+
+}  // namespace pclmi

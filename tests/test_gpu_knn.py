@@ -1,0 +1,149 @@
+"""GPU parity: pclmi_knn (HIP, through the C ABI) vs the CPU oracle, bit-exact."""
+import json
+
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from pcl_amd import capi as c
+    assert c.device_count() > 0, "no HIP device: the GPU tests must run on the MI355X box"
+    return c
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import pcl_oracle
+    return pcl_oracle
+
+
+def _check(capi, orc, pts, q, k, brute=True):
+    t = capi.Tree(pts)
+    gi, gd = t.knn(q, k)
+    oi, od = (orc.knn_brute if brute else (lambda a, b, kk: orc.Tree(a).knn(b, kk, nthreads=8)))(pts, q, k)
+    assert gi.shape == oi.shape
+    bad = np.nonzero((gi != oi).any(axis=1) | (gd.view(np.int32) != od.view(np.int32)).any(axis=1))[0]
+    assert len(bad) == 0, "first mismatch at query %d:\n gpu %s %s\n cpu %s %s" % (
+        bad[0], gi[bad[0]], gd[bad[0]], oi[bad[0]], od[bad[0]])
+    t.close()
+
+
+def test_known_answer_10_points(capi):
+    kat = util.golden("kdtree_kat.json")
+    pts = np.array(kat["points"], np.float32)
+    q = np.array([kat["query"]], np.float32)
+    for case in kat["cases"]:
+        alpha = np.array(case["alpha"], np.float32)
+        p, qq = pts * alpha, q * alpha
+        if case["dims"] == 2:
+            p = p.copy(); p[:, 2] = 0
+            qq = qq.copy(); qq[:, 2] = 0
+        t = capi.Tree(p)
+        idx, d2 = t.knn(qq, kat["k"])
+        assert idx[0].tolist() == case["indices"], case["name"]
+        assert np.allclose(d2[0], case["distances"], atol=kat["distance_tol"])
+
+
+def test_bun_1nn_matches_golden(capi):
+    api = util.golden("registration_api.json")
+    src, tgt = util.bun0(), util.bun4()
+    t = capi.Tree(tgt)
+    idx, d2 = t.knn(src, 1)
+    exp = np.array(api["correspondences_original"])
+    assert idx[:, 0].tolist() == exp[:, 1].tolist()
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 8, 10, 16, 20, 32, 33, 64, 512])
+def test_uniform_1200_all_k(capi, orc, k):
+    # recipe of test/test_search.cpp:571-617 (1200 uniform points), k list of :624-631 and more
+    pts = util.uniform_cloud(1200, 11)
+    q = util.uniform_cloud(777, 12)
+    _check(capi, orc, pts, q, k)
+
+
+@pytest.mark.parametrize("k", [1, 8, 16, 20, 32, 40])
+def test_grid_ties(capi, orc, k):
+    # 11^3 grid: every query has many exactly-equal distances -> exercises (d2, index) order
+    pts = util.grid_cloud()
+    q = np.concatenate([pts[::7], np.array([[0.01, 0.01, 0.01], [0, 0, 0], [0.05, 0.05, 0.05]], np.float32),
+                        pts[:200] + np.float32(0.05)])
+    _check(capi, orc, pts, q, k)
+
+
+def test_duplicates_and_tiny_clouds(capi, orc):
+    rng = np.random.default_rng(5)
+    base = rng.random((40, 3), dtype=np.float32)
+    pts = np.repeat(base, 30, axis=0)  # 1200 points, each value 30 times: ties beyond any bucket
+    q = np.concatenate([base, rng.random((100, 3), dtype=np.float32)])
+    for k in (1, 4, 16, 31, 32, 45):
+        _check(capi, orc, pts, q, k)
+    for n in (1, 2, 3, 15, 16, 17, 33):
+        p = rng.random((n, 3), dtype=np.float32)
+        for k in (1, 2, 16, 50):
+            _check(capi, orc, p, q[:70], k)
+
+
+def test_nan_rows_and_index_subset(capi, orc):
+    # sparse cloud of test/test_search.cpp:582-599: every 11th point NaN; plus an index view
+    pts = util.uniform_cloud(1200, 21)
+    pts[::11] = np.nan
+    q = util.uniform_cloud(300, 22)
+    t = capi.Tree(pts)
+    valid = np.nonzero(np.isfinite(pts).all(axis=1))[0]
+    assert len(t) == len(valid)
+    gi, gd = t.knn(q, 8)
+    oi, od = orc.knn_brute(pts[valid], q, 8)
+    assert np.array_equal(gi, valid[oi]) and np.array_equal(gd, od)
+    rng = np.random.default_rng(3)
+    view = rng.permutation(1200)[:120].astype(np.int32)
+    t2 = capi.Tree(pts, indices=view)
+    vv = np.array([i for i in view if np.isfinite(pts[i]).all()])
+    gi, gd = t2.knn(q, 5)
+    assert np.isin(gi, vv).all()
+    # distances are exact; indices are rows of the whole cloud
+    oi, od = orc.knn_brute(pts[vv], q, 5)
+    assert np.array_equal(gd, od)
+    recomputed = ((q[:, None, :] - pts[gi]) ** 2)
+    assert np.array_equal(((recomputed[..., 0] + recomputed[..., 1]) + recomputed[..., 2]).astype(np.float32), gd)
+
+
+def test_empty_and_errors(capi):
+    t = capi.Tree(np.zeros((0, 3), np.float32))
+    assert len(t) == 0
+    idx, d2 = t.knn(np.zeros((4, 3), np.float32), 3)
+    assert idx.shape == (4, 0)
+    t2 = capi.Tree(util.uniform_cloud(100, 1))
+    with pytest.raises(capi.PclmiError):
+        t2.knn(np.zeros((4, 3), np.float32), 0)
+    idx, d2 = t2.knn(np.zeros((0, 3), np.float32), 3)
+    assert idx.shape == (0, 3)
+    idx, d2 = t2.knn(util.uniform_cloud(5, 2), 1000)  # k clamped to 100 (kdtree_flann.hpp:85-86)
+    assert idx.shape == (5, 100) and np.all(np.sort(idx, axis=1) == np.arange(100))
+
+
+@pytest.mark.parametrize("n,nq,k", [(100_000, 20_000, 16), (100_000, 20_000, 1), (250_000, 10_000, 32)])
+def test_large_vs_oracle_tree(capi, orc, n, nq, k):
+    # uniform cube [0,1024)^3 as BASELINE C2 (scaled down so the CPU oracle finishes in seconds)
+    pts = util.uniform_cloud(n, 20260101, 0, 1024)
+    q = util.uniform_cloud(nq, 20260102, 0, 1024)
+    _check(capi, orc, pts, q, k, brute=False)
+
+
+def test_surface_like_and_far_queries(capi, orc):
+    rng = np.random.default_rng(9)
+    # points on a few planes + noise (real clouds are 2-manifolds), queries partly far outside
+    n = 60_000
+    uv = rng.random((n, 2), dtype=np.float32) * 100
+    plane = rng.integers(0, 4, n)
+    pts = np.zeros((n, 3), np.float32)
+    pts[:, 0] = uv[:, 0]
+    pts[:, 1] = uv[:, 1]
+    pts[:, 2] = plane * 7 + rng.normal(0, 0.05, n).astype(np.float32)
+    q = np.concatenate([pts[::50] + np.float32(0.3), rng.random((500, 3), dtype=np.float32) * 1000 - 300])
+    _check(capi, orc, pts, q.astype(np.float32), 16, brute=False)
+    _check(capi, orc, pts, q.astype(np.float32), 1, brute=False)
