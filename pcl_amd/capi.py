@@ -134,7 +134,7 @@ class Tree:
         self.cloud = _pts(cloud)
         idx = None if indices is None else np.ascontiguousarray(indices, np.int32)
         h = C.c_void_p()
-        _check(lib.pclmi_tree_create(self.cloud.ctypes.data, len(self.cloud), self.cloud.strides[0],
+        _check(lib.pclmi_tree_create(self.cloud.ctypes.data, len(self.cloud), self.cloud.shape[1] * 4,
                                      None if idx is None else idx.ctypes.data, 0 if idx is None else len(idx), 0,
                                      C.byref(h)))
         self.h = h
@@ -160,7 +160,7 @@ class Tree:
         idx = np.empty((len(q), ke), np.int32)
         d2 = np.empty((len(q), ke), np.float32)
         keff = C.c_int(0)
-        _check(load_library().pclmi_knn(self.h, q.ctypes.data, len(q), q.strides[0], k, idx.ctypes.data,
+        _check(load_library().pclmi_knn(self.h, q.ctypes.data, len(q), q.shape[1] * 4, k, idx.ctypes.data,
                                         d2.ctypes.data, C.byref(keff)))
         assert keff.value == ke
         return idx, d2
@@ -175,7 +175,7 @@ class Tree:
         q = _pts(queries)
         offsets = np.zeros(len(q) + 1, np.uint64)
         pi, pd = C.c_void_p(), C.c_void_p()
-        _check(lib.pclmi_radius(self.h, q.ctypes.data, len(q), q.strides[0], float(radius), max_nn,
+        _check(lib.pclmi_radius(self.h, q.ctypes.data, len(q), q.shape[1] * 4, float(radius), max_nn,
                                 int(sorted_results), offsets.ctypes.data, C.byref(pi), C.byref(pd)))
         total = int(offsets[-1])
         if total:
@@ -195,7 +195,7 @@ def correspondences(target_tree, src, max_distance=float(np.sqrt(np.finfo(np.flo
     cap = len(s) if si is None else len(si)
     out = np.zeros(cap, CORR_DTYPE)
     n = C.c_size_t(0)
-    _check(lib.pclmi_correspondences(target_tree.h, s.ctypes.data, len(s), s.strides[0],
+    _check(lib.pclmi_correspondences(target_tree.h, s.ctypes.data, len(s), s.shape[1] * 4,
                                      None if si is None else si.ctypes.data, 0 if si is None else len(si),
                                      max_distance, out.ctypes.data, C.byref(n)))
     return out[: n.value].copy()
@@ -209,9 +209,9 @@ def correspondences_reciprocal(target_tree, source_tree, src, tgt,
     cap = len(s) if si is None else len(si)
     out = np.zeros(cap, CORR_DTYPE)
     n = C.c_size_t(0)
-    _check(lib.pclmi_correspondences_reciprocal(target_tree.h, source_tree.h, s.ctypes.data, len(s), s.strides[0],
+    _check(lib.pclmi_correspondences_reciprocal(target_tree.h, source_tree.h, s.ctypes.data, len(s), s.shape[1] * 4,
                                                 None if si is None else si.ctypes.data,
-                                                0 if si is None else len(si), t.ctypes.data, len(t), t.strides[0],
+                                                0 if si is None else len(si), t.ctypes.data, len(t), t.shape[1] * 4,
                                                 max_distance, out.ctypes.data, C.byref(n)))
     return out[: n.value].copy()
 
@@ -223,8 +223,8 @@ def estimate_rigid_svd(src, tgt, src_idx=None, tgt_idx=None):
     ti = None if tgt_idx is None else np.ascontiguousarray(tgt_idx, np.int32)
     n = len(si) if si is not None else (len(ti) if ti is not None else len(s))
     T = np.zeros(16, np.float32)
-    _check(lib.pclmi_estimate_rigid_svd(s.ctypes.data, len(s), s.strides[0], None if si is None else si.ctypes.data,
-                                        t.ctypes.data, len(t), t.strides[0], None if ti is None else ti.ctypes.data,
+    _check(lib.pclmi_estimate_rigid_svd(s.ctypes.data, len(s), s.shape[1] * 4, None if si is None else si.ctypes.data,
+                                        t.ctypes.data, len(t), t.shape[1] * 4, None if ti is None else ti.ctypes.data,
                                         n, T.ctypes.data_as(c_f32p)))
     return T.reshape(4, 4)
 
@@ -232,7 +232,7 @@ def estimate_rigid_svd(src, tgt, src_idx=None, tgt_idx=None):
 def transform(points, T):
     out = _pts(points).copy()
     Tm = np.ascontiguousarray(T, np.float32).reshape(16)
-    _check(load_library().pclmi_transform(out.ctypes.data, len(out), out.strides[0], Tm.ctypes.data_as(c_f32p)))
+    _check(load_library().pclmi_transform(out.ctypes.data, len(out), out.shape[1] * 4, Tm.ctypes.data_as(c_f32p)))
     return out
 
 
@@ -251,7 +251,7 @@ def icp_align(target_tree, src, params=None, guess=None):
     out = np.zeros((len(s), 4), np.float32)
     st = IcpStats()
     g = None if guess is None else np.ascontiguousarray(guess, np.float32).reshape(16)
-    rc = lib.pclmi_icp_align(C.byref(p), target_tree.h, s.ctypes.data, len(s), s.strides[0],
+    rc = lib.pclmi_icp_align(C.byref(p), target_tree.h, s.ctypes.data, len(s), s.shape[1] * 4,
                              None if g is None else g.ctypes.data_as(c_f32p), T.ctypes.data_as(c_f32p),
                              out.ctypes.data, C.byref(st))
     if rc not in (0, 6):
@@ -263,7 +263,7 @@ def fitness_score(target_tree, src, T, max_range=float(np.finfo(np.float64).max)
     s = _pts(src)
     Tm = np.ascontiguousarray(T, np.float32).reshape(16)
     score = C.c_double(0)
-    _check(load_library().pclmi_fitness_score(target_tree.h, s.ctypes.data, len(s), s.strides[0],
+    _check(load_library().pclmi_fitness_score(target_tree.h, s.ctypes.data, len(s), s.shape[1] * 4,
                                               Tm.ctypes.data_as(c_f32p), max_range, C.byref(score)))
     return score.value
 
@@ -285,7 +285,7 @@ class IcpShard:
         self.src = _pts(src)
         g = None if guess is None else np.ascontiguousarray(guess, np.float32).reshape(16)
         h = C.c_void_p()
-        _check(lib.pclmi_icp_begin(target_tree.h, self.src.ctypes.data, len(self.src), self.src.strides[0],
+        _check(lib.pclmi_icp_begin(target_tree.h, self.src.ctypes.data, len(self.src), self.src.shape[1] * 4,
                                    None if g is None else g.ctypes.data_as(c_f32p), C.byref(h)))
         self.h = h
         self.n = len(self.src)
