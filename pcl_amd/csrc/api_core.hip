@@ -29,28 +29,31 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line) {
   return PCLMI_ERR_HIP;
 }
 
-int Workspace::ensure_queries(size_t nq) {
-  if (nq <= cap_q) return PCLMI_OK;
-  size_t cap = nq + nq / 8 + 1024;
-  if (keys_in) (void)hipFree(keys_in);
-  if (keys_out) (void)hipFree(keys_out);
-  if (vals_in) (void)hipFree(vals_in);
-  if (vals_out) (void)hipFree(vals_out);
-  if (sort_tmp) (void)hipFree(sort_tmp);
-  keys_in = keys_out = nullptr;
-  vals_in = vals_out = nullptr;
-  sort_tmp = nullptr;
-  cap_q = 0;
-  PCLMI_HIP(hipMalloc(&keys_in, cap * 4));
-  PCLMI_HIP(hipMalloc(&keys_out, cap * 4));
-  PCLMI_HIP(hipMalloc(&vals_in, cap * 4));
-  PCLMI_HIP(hipMalloc(&vals_out, cap * 4));
-  size_t tmp = 0;
-  PCLMI_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, keys_in, keys_out, vals_in, vals_out, (int)cap, 0, 30,
-                                               (hipStream_t) nullptr));
-  cap_tmp = tmp + 256;
-  PCLMI_HIP(hipMalloc(&sort_tmp, cap_tmp));
-  cap_q = cap;
+int Workspace::ensure_queries(size_t nq, size_t nbins) {
+  if (nq > cap_q) {
+    size_t cap = nq + nq / 8 + 1024;
+    if (keys_in) (void)hipFree(keys_in);
+    if (vals_out) (void)hipFree(vals_out);
+    keys_in = nullptr;
+    vals_out = nullptr;
+    cap_q = 0;
+    PCLMI_HIP(hipMalloc(&keys_in, cap * 4));
+    PCLMI_HIP(hipMalloc(&vals_out, cap * 4));
+    cap_q = cap;
+  }
+  if (nbins > cap_bins) {
+    if (hist) (void)hipFree(hist);
+    if (sort_tmp) (void)hipFree(sort_tmp);
+    hist = nullptr;
+    sort_tmp = nullptr;
+    cap_bins = 0;
+    PCLMI_HIP(hipMalloc(&hist, nbins * 4));
+    size_t tmp = 0;
+    PCLMI_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, hist, hist, (int)nbins, (hipStream_t) nullptr));
+    cap_tmp = tmp + 256;
+    PCLMI_HIP(hipMalloc(&sort_tmp, cap_tmp));
+    cap_bins = nbins;
+  }
   return PCLMI_OK;
 }
 
@@ -67,9 +70,8 @@ int Workspace::ensure_scratch(size_t bytes) {
 
 void Workspace::release() {
   if (keys_in) (void)hipFree(keys_in);
-  if (keys_out) (void)hipFree(keys_out);
-  if (vals_in) (void)hipFree(vals_in);
   if (vals_out) (void)hipFree(vals_out);
+  if (hist) (void)hipFree(hist);
   if (sort_tmp) (void)hipFree(sort_tmp);
   if (scratch) (void)hipFree(scratch);
   *this = Workspace();

@@ -37,7 +37,25 @@ typedef const f8v __attribute__((address_space(4))) *cbox_ptr;    // one node bo
 typedef const f16v __attribute__((address_space(4))) *cgrp_ptr;   // 64-byte line
 
 constexpr int L = kLeafSize;
-constexpr int G = L / 4;  // point groups per bucket: [x0..3 | y0..3 | z0..3 | idx0..3]
+constexpr int G = L / 4;
+
+#ifdef PCLMI_STATS
+// development statistics (never compiled into the shipped library)
+__device__ unsigned long long g_stats[16];
+#define STAT_DECL unsigned long long sacc_[16] = {0}
+#define STAT_ADD(i, v) do { sacc_[i] += (unsigned long long)(v); } while (0)
+#define STAT_FLUSH do { if (lane == 0) { _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&g_stats[i_], sacc_[i_]); } } while (0)
+// cycle stamps: one statement = s_memtime + its wait, fenced for the scheduler (diagnostic build only)
+#define STAMP(var) unsigned long long var; __builtin_amdgcn_sched_barrier(0); \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0)
+#define STAMP_ACC(i, t1, t0) STAT_ADD(i, (t1) - (t0))
+#else
+#define STAT_DECL do { } while (0)
+#define STAT_FLUSH do { } while (0)
+#define STAT_ADD(i, v) do { } while (0)
+#define STAMP(var) do { } while (0)
+#define STAMP_ACC(i, t1, t0) do { } while (0)
+#endif  // point groups per bucket: [x0..3 | y0..3 | z0..3 | idx0..3]
 
 __device__ __forceinline__ float sq3(float dx, float dy, float dz) {
   // one rounding per operation, fixed order: ((dx*dx + dy*dy) + dz*dz)
@@ -52,6 +70,33 @@ __device__ __forceinline__ float box_dist(float qx, float qy, float qz, float lx
   float dy = fmaxf(fmaxf(ly - qy, qy - hy), 0.f);
   float dz = fmaxf(fmaxf(lz - qz, qz - hz), 0.f);
   return sq3(dx, dy, dz);
+}
+
+// Packed fp32 (v_pk_add_f32 / v_pk_mul_f32): two candidates or two boxes per instruction.  Each
+// half is an ordinary IEEE fp32 operation, so results are bit-identical to sq3 / box_dist.
+typedef float f2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f2v sq3_pk(f2v dx, f2v dy, f2v dz) {
+#pragma clang fp contract(off)
+  const f2v xx = dx * dx, yy = dy * dy, zz = dz * dz;
+  const f2v s = xx + yy;
+  return s + zz;
+}
+
+__device__ __forceinline__ f2v box_dist_pk(f2v qx, f2v qy, f2v qz, f2v lx, f2v ly, f2v lz, f2v hx, f2v hy,
+                                           f2v hz) {
+#pragma clang fp contract(off)
+  const f2v ax = lx - qx, bx = qx - hx;
+  const f2v ay = ly - qy, by = qy - hy;
+  const f2v az = lz - qz, bz = qz - hz;
+  f2v dx, dy, dz;
+  dx.x = fmaxf(fmaxf(ax.x, bx.x), 0.f);
+  dx.y = fmaxf(fmaxf(ax.y, bx.y), 0.f);
+  dy.x = fmaxf(fmaxf(ay.x, by.x), 0.f);
+  dy.y = fmaxf(fmaxf(ay.y, by.y), 0.f);
+  dz.x = fmaxf(fmaxf(az.x, bz.x), 0.f);
+  dz.y = fmaxf(fmaxf(az.y, bz.y), 0.f);
+  return sq3_pk(dx, dy, dz);
 }
 
 __device__ __forceinline__ unsigned long long make_key(float d, int i) {
@@ -139,6 +184,129 @@ __device__ __forceinline__ void sort_keys(unsigned long long (&k)[N]) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Shared prologue: XCD-aware wave -> query-chunk assignment and query load.
+struct LaneQuery {
+  float x, y, z;
+  int qi;
+  bool alive;       // lane maps to a query row
+  bool searchable;  // ... and that query is finite
+};
+
+template <int WPB>
+__device__ __forceinline__ bool load_lane_query(const float *__restrict__ q, int q_stride_f,
+                                                const int *__restrict__ order, int nq, LaneQuery &o) {
+  const int lane = threadIdx.x & 63;
+  const int wib = threadIdx.x >> 6;
+  // blocks b, b+8, b+16 ... share an XCD (and its L2): give each XCD one contiguous range of the
+  // sorted queries so that its L2 holds one part of the tree.  (Placement only affects speed.)
+  const int per = (gridDim.x + 7) >> 3;
+  const int blk = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  const int slot = (blk * WPB + wib) * 64 + lane;
+  if (__builtin_amdgcn_readfirstlane(slot) >= nq) return false;  // whole wave past the end
+  o.alive = slot < nq;
+  o.qi = o.alive ? (order ? order[slot] : slot) : 0;
+  o.x = o.y = o.z = __builtin_nanf("");  // dead lanes: every comparison is false
+  if (o.alive) {
+    const float *p = q + (size_t)o.qi * q_stride_f;
+    o.x = p[0];
+    o.y = p[1];
+    o.z = p[2];
+  }
+  // Lanes past the end and non-finite queries must never steer the wave: their coordinates are
+  // NaN (no candidate ever passes) and the callers give them a NEGATIVE bound, because
+  // box_dist(NaN) is 0 (fmax drops NaNs) and would otherwise "need" every box of the tree.
+  o.searchable = o.alive && isfinite(o.x) && isfinite(o.y) && isfinite(o.z);
+  if (!o.searchable) o.x = o.y = o.z = __builtin_nanf("");
+  return true;
+}
+
+// Per-lane pre-pass: walk down to a nearby bucket (towards the nearer child box), scan it and its
+// sibling bucket with ordinary vector loads, and return the K-th smallest distance found.  This
+// is only an UPPER BOUND on the true K-th distance (FLT_MAX when fewer than K points were seen);
+// starting the union traversal with it prunes the far subtrees from the first step on.
+template <int K>
+__device__ __forceinline__ float lane_bound(const TreeView &t, float qx, float qy, float qz) {
+  const int M = t.M;
+  int node = 1;
+  while (node < M) {
+    const float4 *b = reinterpret_cast<const float4 *>(t.box + (size_t)node * 16);
+    const float4 b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
+    const float m0 = box_dist(qx, qy, qz, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y);
+    const float m1 = box_dist(qx, qy, qz, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y);
+    node = 2 * node + (m1 < m0 ? 1 : 0);
+  }
+  float a[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) a[j] = 3.402823466e+38f;
+  // scan the NB sibling buckets around the one reached (>= 2K points when they are all full)
+  constexpr int NB = (2 * K / L) > 2 ? (2 * K / L) : 2;
+  const int first = node & ~(NB - 1);
+#pragma unroll 1
+  for (int s = 0; s < NB; ++s) {
+    const int bn = first + s;
+    if (bn < M || bn > 2 * M - 1) continue;
+    const float4 *rec = reinterpret_cast<const float4 *>(t.leaf + (size_t)(bn - M) * (4 * L));
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const float4 X = rec[g * 4 + 0], Y = rec[g * 4 + 1], Z = rec[g * 4 + 2];
+      list_insert<K>(a, sq3(qx - X.x, qy - Y.x, qz - Z.x));
+      list_insert<K>(a, sq3(qx - X.y, qy - Y.y, qz - Z.y));
+      list_insert<K>(a, sq3(qx - X.z, qy - Y.z, qz - Z.z));
+      list_insert<K>(a, sq3(qx - X.w, qy - Y.w, qz - Z.w));
+    }
+  }
+  return a[K - 1];
+}
+
+// One step of the wave-uniform traversal at inner node `node`: tests the 4 grandchildren at once
+// when both children are inner nodes (their boxes are two adjacent 64-byte lines), else the 2
+// children; pushes the boxes some lane still needs, nearest (by lane majority) on top.
+__device__ __forceinline__ void expand_inner(LaneStack &st, const cgrp_ptr box2, int node, int M, float qx,
+                                             float qy, float qz, float tau) {
+  if (2 * node + 1 < M) {
+    const f16v ba = box2[2 * node], bb = box2[2 * node + 1];
+    const f2v q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
+    const f2v m01 = box_dist_pk(q2x, q2y, q2z, f2v{ba[0], ba[8]}, f2v{ba[1], ba[9]}, f2v{ba[2], ba[10]},
+                                f2v{ba[3], ba[11]}, f2v{ba[4], ba[12]}, f2v{ba[5], ba[13]});
+    const f2v m23 = box_dist_pk(q2x, q2y, q2z, f2v{bb[0], bb[8]}, f2v{bb[1], bb[9]}, f2v{bb[2], bb[10]},
+                                f2v{bb[3], bb[11]}, f2v{bb[4], bb[12]}, f2v{bb[5], bb[13]});
+    const float m0 = m01.x, m1 = m01.y, m2 = m23.x, m3 = m23.y;
+    const bool n0 = __any(m0 <= tau), n1 = __any(m1 <= tau), n2 = __any(m2 <= tau), n3 = __any(m3 <= tau);
+    const bool a_first = __popcll(__ballot(fminf(m0, m1) <= fminf(m2, m3))) >= 32;
+    const bool f01 = __popcll(__ballot(m0 <= m1)) >= 32;
+    const bool f23 = __popcll(__ballot(m2 <= m3)) >= 32;
+    const int g = 4 * node;
+#define PCLMI_PUSH_PAIR(base, lowfirst, nlo, nhi) \
+  do {                                            \
+    if (lowfirst) {                               \
+      if (nhi) st.push((base) + 1);               \
+      if (nlo) st.push(base);                     \
+    } else {                                      \
+      if (nlo) st.push(base);                     \
+      if (nhi) st.push((base) + 1);               \
+    }                                             \
+  } while (0)
+    if (a_first) {
+      PCLMI_PUSH_PAIR(g + 2, f23, n2, n3);
+      PCLMI_PUSH_PAIR(g, f01, n0, n1);
+    } else {
+      PCLMI_PUSH_PAIR(g, f01, n0, n1);
+      PCLMI_PUSH_PAIR(g + 2, f23, n2, n3);
+    }
+  } else {
+    const f16v b = box2[node];
+    const f2v q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
+    const f2v m01 = box_dist_pk(q2x, q2y, q2z, f2v{b[0], b[8]}, f2v{b[1], b[9]}, f2v{b[2], b[10]},
+                                f2v{b[3], b[11]}, f2v{b[4], b[12]}, f2v{b[5], b[13]});
+    const float m0 = m01.x, m1 = m01.y;
+    const bool n0 = __any(m0 <= tau), n1 = __any(m1 <= tau);
+    const bool f01 = __popcll(__ballot(m0 <= m1)) >= 32;
+    PCLMI_PUSH_PAIR(2 * node, f01, n0, n1);
+  }
+#undef PCLMI_PUSH_PAIR
+}
+
+// ---------------------------------------------------------------------------------------------
 // K >= 2 : register distance list + LDS append buffer.  WPB waves per block, C buffer entries.
 template <int K, int C, int WPB>
 __global__ __launch_bounds__(64 * WPB) void knn_union_kernel(TreeView t, const float *__restrict__ q,
@@ -146,31 +314,25 @@ __global__ __launch_bounds__(64 * WPB) void knn_union_kernel(TreeView t, const f
                                                               const int *__restrict__ order, int nq,
                                                               int k_out, int *__restrict__ out_idx,
                                                               float *__restrict__ out_d2) {
-  static_assert(C >= K + L, "buffer must hold the K best plus one bucket");
+  static_assert(C >= K + 8, "buffer must hold the K best plus two groups of appends");
   __shared__ uint2 lds[WPB][C][64];
   const int lane = threadIdx.x & 63;
-  const int wib = threadIdx.x >> 6;
-  // XCD-aware chunk assignment: blocks b, b+8, b+16 ... share an XCD (and its L2); give each
-  // XCD one contiguous range of the sorted queries so that its L2 holds one part of the tree.
-  const int nblk = gridDim.x;
-  const int per = (nblk + 7) >> 3;
-  const int blk = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-  const int slot = (blk * WPB + wib) * 64 + lane;
-  if (__builtin_amdgcn_readfirstlane(slot) >= nq) return;  // whole wave past the end
-  const bool alive = slot < nq;
-  const int qi = alive ? (order ? order[slot] : slot) : 0;
-  float qx = __builtin_nanf(""), qy = qx, qz = qx;
-  if (alive) {
-    const float *p = q + (size_t)qi * q_stride_f;
-    qx = p[0];
-    qy = p[1];
-    qz = p[2];
-  }
-  uint2(*buf)[64] = lds[wib];
+  LaneQuery lq;
+  if (!load_lane_query<WPB>(q, q_stride_f, order, nq, lq)) return;
+  const float qx = lq.x, qy = lq.y, qz = lq.z;
+  uint2(*buf)[64] = lds[threadIdx.x >> 6];
+  STAT_DECL;
 
+  // a[] = the K smallest distances seen so far, capped by the pre-pass bound: at least K points lie
+  // within `bound`, so min(bound, K-th smallest seen) is always a valid bound and ends exact.
+  STAMP(ts0);
+  const float bound = lq.searchable ? lane_bound<K>(t, qx, qy, qz) : -1.f;
+  asm volatile("" :: "v"(bound));
+  STAMP(ts1);
+  STAMP_ACC(8, ts1, ts0);
   float a[K];
 #pragma unroll
-  for (int j = 0; j < K; ++j) a[j] = 3.402823466e+38f;  // FLT_MAX: padded slots (d2=+inf) never pass
+  for (int j = 0; j < K; ++j) a[j] = bound;
   int cnt = 0;
 
   LaneStack st{0, 0, lane};
@@ -184,45 +346,69 @@ __global__ __launch_bounds__(64 * WPB) void knn_union_kernel(TreeView t, const f
     const int node = st.pop();
     if (node >= M) {
       // ---- bucket: re-test its box against the (possibly tighter) bound, then scan it
+      STAMP(tb0);
       const f8v b = box[node];
       const cgrp_ptr rec = leaf + (size_t)(node - M) * G;
       f16v grp[G];
 #pragma unroll
       for (int g = 0; g < G; ++g) grp[g] = rec[g];
+#ifdef PCLMI_STATS
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+      STAMP(tb1);
+      STAMP_ACC(9, tb1, tb0);
       const float md = box_dist(qx, qy, qz, b[0], b[1], b[2], b[3], b[4], b[5]);
+      STAT_ADD(1, 1);
       if (!__any(md <= a[K - 1])) continue;
+      STAT_ADD(2, 1);
+      const f2v q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
 #pragma unroll
       for (int g = 0; g < G; ++g) {
+        float dd[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f2v d2 = sq3_pk(q2x - f2v{grp[g][2 * h], grp[g][2 * h + 1]},
+                                q2y - f2v{grp[g][4 + 2 * h], grp[g][5 + 2 * h]},
+                                q2z - f2v{grp[g][8 + 2 * h], grp[g][9 + 2 * h]});
+          dd[2 * h] = d2.x;
+          dd[2 * h + 1] = d2.y;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float d = sq3(qx - grp[g][j], qy - grp[g][4 + j], qz - grp[g][8 + j]);
-          if (d <= a[K - 1]) {
-            buf[cnt][lane] = make_uint2(__float_as_uint(d), __float_as_uint(grp[g][12 + j]));
-            ++cnt;
+          const float d = dd[j];
+          const bool pass = d <= a[K - 1];
+          if (__any(pass)) {  // wave-uniform: the insert is a no-op for lanes that do not pass
+            STAT_ADD(3, 1);
+            STAT_ADD(4, __builtin_amdgcn_readfirstlane(pass ? 1 : 0));
+            if (pass) {
+              buf[cnt][lane] = make_uint2(__float_as_uint(d), __float_as_uint(grp[g][12 + j]));
+              ++cnt;
+            }
+            list_insert<K>(a, d);
           }
-          list_insert<K>(a, d);
+        }
+        // keep room for the next group of 4 appends
+        if (__any(cnt > C - 4)) {
+          STAT_ADD(5, 1);
+          STAMP(tc0);
+          cnt = compact_buffer<K, C>(buf, lane, cnt, a[K - 1]);
+          STAMP(tc1);
+          STAMP_ACC(10, tc1, tc0);
         }
       }
-      if (__any(cnt > C - L)) cnt = compact_buffer<K, C>(buf, lane, cnt, a[K - 1]);
+      STAMP(tb2);
+      STAMP_ACC(11, tb2, tb1);
     } else {
-      // ---- inner node: both children's boxes are one 64-byte line
-      const f16v b = box2[node];
-      const float m0 = box_dist(qx, qy, qz, b[0], b[1], b[2], b[3], b[4], b[5]);
-      const float m1 = box_dist(qx, qy, qz, b[8], b[9], b[10], b[11], b[12], b[13]);
-      const float tau = a[K - 1];
-      const bool n0 = __any(m0 <= tau), n1 = __any(m1 <= tau);
-      // nearer child (by lane majority) is pushed last, i.e. visited first
-      const bool first0 = __popcll(__ballot(m0 <= m1)) >= 32;
-      const int c0 = 2 * node, c1 = 2 * node + 1;
-      if (first0) {
-        if (n1) st.push(c1);
-        if (n0) st.push(c0);
-      } else {
-        if (n0) st.push(c0);
-        if (n1) st.push(c1);
-      }
+      STAT_ADD(0, 1);
+      STAMP(ti0);
+      expand_inner(st, box2, node, M, qx, qy, qz, a[K - 1]);
+      STAMP(ti1);
+      STAMP_ACC(12, ti1, ti0);
     }
   }
+  STAMP(tf0);
+  STAMP_ACC(13, tf0, ts0);
+  STAT_FLUSH;
 
   // ---- final: filter with the exact k-th distance, sort the survivors by (d2, index)
   cnt = compact_buffer<K, C>(buf, lane, cnt, a[K - 1]);
@@ -233,9 +419,9 @@ __global__ __launch_bounds__(64 * WPB) void knn_union_kernel(TreeView t, const f
     key[j] = j < cnt ? (((unsigned long long)v.x << 32) | v.y) : ~0ull;
   }
   sort_keys<K>(key);
-  if (alive) {
-    int *oi = out_idx + (size_t)qi * k_out;
-    float *od = out_d2 + (size_t)qi * k_out;
+  if (lq.alive) {
+    int *oi = out_idx + (size_t)lq.qi * k_out;
+    float *od = out_d2 + (size_t)lq.qi * k_out;
 #pragma unroll
     for (int j = 0; j < K; ++j) {
       if (j < k_out) {
@@ -255,23 +441,11 @@ __global__ __launch_bounds__(64 * WPB) void knn1_union_kernel(TreeView t, const 
                                                                int *__restrict__ out_idx,
                                                                float *__restrict__ out_d2) {
   const int lane = threadIdx.x & 63;
-  const int wib = threadIdx.x >> 6;
-  const int nblk = gridDim.x;
-  const int per = (nblk + 7) >> 3;
-  const int blk = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-  const int slot = (blk * WPB + wib) * 64 + lane;
-  if (__builtin_amdgcn_readfirstlane(slot) >= nq) return;
-  const bool alive = slot < nq;
-  const int qi = alive ? (order ? order[slot] : slot) : 0;
-  float qx = __builtin_nanf(""), qy = qx, qz = qx;
-  if (alive) {
-    const float *p = q + (size_t)qi * q_stride_f;
-    qx = p[0];
-    qy = p[1];
-    qz = p[2];
-  }
+  LaneQuery lq;
+  if (!load_lane_query<WPB>(q, q_stride_f, order, nq, lq)) return;
+  const float qx = lq.x, qy = lq.y, qz = lq.z;
   unsigned long long best = make_key(3.402823466e+38f, 0x7fffffff);
-  float tau = 3.402823466e+38f;
+  float tau = lq.searchable ? lane_bound<1>(t, qx, qy, qz) : -1.f;
   LaneStack st{0, 0, lane};
   st.push(1);
   const cbox_ptr box = (cbox_ptr)t.box;
@@ -287,35 +461,28 @@ __global__ __launch_bounds__(64 * WPB) void knn1_union_kernel(TreeView t, const 
 #pragma unroll
       for (int g = 0; g < G; ++g) grp[g] = rec[g];
       if (!__any(box_dist(qx, qy, qz, b[0], b[1], b[2], b[3], b[4], b[5]) <= tau)) continue;
+      const f2v q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
 #pragma unroll
       for (int g = 0; g < G; ++g) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float d = sq3(qx - grp[g][j], qy - grp[g][4 + j], qz - grp[g][8 + j]);
-          const unsigned long long key = make_key(d, __float_as_int(grp[g][12 + j]));
-          best = key < best ? key : best;
+        for (int h = 0; h < 2; ++h) {
+          const f2v d2 = sq3_pk(q2x - f2v{grp[g][2 * h], grp[g][2 * h + 1]},
+                                q2y - f2v{grp[g][4 + 2 * h], grp[g][5 + 2 * h]},
+                                q2z - f2v{grp[g][8 + 2 * h], grp[g][9 + 2 * h]});
+          const unsigned long long k0 = make_key(d2.x, __float_as_int(grp[g][12 + 2 * h]));
+          const unsigned long long k1 = make_key(d2.y, __float_as_int(grp[g][13 + 2 * h]));
+          best = k0 < best ? k0 : best;
+          best = k1 < best ? k1 : best;
         }
       }
-      tau = __uint_as_float((unsigned int)(best >> 32));
+      tau = fminf(tau, __uint_as_float((unsigned int)(best >> 32)));
     } else {
-      const f16v b = box2[node];
-      const float m0 = box_dist(qx, qy, qz, b[0], b[1], b[2], b[3], b[4], b[5]);
-      const float m1 = box_dist(qx, qy, qz, b[8], b[9], b[10], b[11], b[12], b[13]);
-      const bool n0 = __any(m0 <= tau), n1 = __any(m1 <= tau);
-      const bool first0 = __popcll(__ballot(m0 <= m1)) >= 32;
-      const int c0 = 2 * node, c1 = 2 * node + 1;
-      if (first0) {
-        if (n1) st.push(c1);
-        if (n0) st.push(c0);
-      } else {
-        if (n0) st.push(c0);
-        if (n1) st.push(c1);
-      }
+      expand_inner(st, box2, node, M, qx, qy, qz, tau);
     }
   }
-  if (alive) {
-    out_idx[qi] = (int)(unsigned int)(best & 0xffffffffull);
-    out_d2[qi] = __uint_as_float((unsigned int)(best >> 32));
+  if (lq.alive) {
+    out_idx[lq.qi] = lq.searchable ? (int)(unsigned int)(best & 0xffffffffull) : -1;
+    out_d2[lq.qi] = lq.searchable ? __uint_as_float((unsigned int)(best >> 32)) : __builtin_nanf("");
   }
 }
 
@@ -440,9 +607,12 @@ __device__ __forceinline__ unsigned int spread10(unsigned int v) {
   return v;
 }
 
-__global__ void morton_kernel(const float *__restrict__ q, int q_stride_f, int nq, float lox, float loy,
-                              float loz, float sx, float sy, float sz, unsigned int *__restrict__ keys,
-                              int *__restrict__ vals) {
+// Query ordering = counting sort by Morton cell.  Only coherence matters (the order inside a
+// cell is irrelevant and results never depend on it), so one histogram pass, one scan and one
+// scatter pass replace a full radix sort.
+__global__ void cell_count_kernel(const float *__restrict__ q, int q_stride_f, int nq, float lox, float loy,
+                                  float loz, float sx, float sy, float sz, int shift,
+                                  unsigned int *__restrict__ cell, unsigned int *__restrict__ hist) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nq) return;
   const float *p = q + (size_t)i * q_stride_f;
@@ -451,29 +621,57 @@ __global__ void morton_kernel(const float *__restrict__ q, int q_stride_f, int n
   unsigned int ix = (unsigned int)fminf(fmaxf(fx, 0.f), 1023.f);
   unsigned int iy = (unsigned int)fminf(fmaxf(fy, 0.f), 1023.f);
   unsigned int iz = (unsigned int)fminf(fmaxf(fz, 0.f), 1023.f);
-  keys[i] = spread10(ix) | (spread10(iy) << 1) | (spread10(iz) << 2);
-  vals[i] = i;
+  unsigned int c = (spread10(ix) | (spread10(iy) << 1) | (spread10(iz) << 2)) >> shift;
+  cell[i] = c;
+  atomicAdd(&hist[c], 1u);
+}
+
+__global__ void cell_scatter_kernel(const unsigned int *__restrict__ cell, int nq,
+                                    unsigned int *__restrict__ offs, int *__restrict__ order) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  unsigned int pos = atomicAdd(&offs[cell[i]], 1u);
+  order[pos] = i;
 }
 
 }  // namespace
+
+#ifdef PCLMI_STATS
+extern "C" void pclmi_debug_stats(unsigned long long *out, int reset) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stats), sizeof(unsigned long long) * 16);
+  if (reset) {
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stats), z, sizeof(z));
+  }
+}
+#endif
 
 int launch_morton_order(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq,
                         size_t q_stride_f, hipStream_t s, const int32_t **d_order) {
   *d_order = nullptr;
   if (nq <= 64) return PCLMI_OK;  // a single wave: order is irrelevant
-  int rc = w->ensure_queries(nq);
+  // cells: about 4 queries per cell, 2..8 bits per axis
+  int lg = 0;
+  while (((size_t)1 << lg) < nq) ++lg;
+  int bits = ((lg - 2) / 3) * 3;
+  bits = bits < 6 ? 6 : (bits > 24 ? 24 : bits);
+  const size_t nbins = (size_t)1 << bits;
+  int rc = w->ensure_queries(nq, nbins);
   if (rc) return rc;
   float sc[3];
   for (int d = 0; d < 3; ++d) {
     float ext = t->bb_hi[d] - t->bb_lo[d];
     sc[d] = ext > 0.f ? 1024.f / ext : 0.f;
   }
-  hipLaunchKernelGGL(morton_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, d_q,
-                     (int)q_stride_f, (int)nq, t->bb_lo[0], t->bb_lo[1], t->bb_lo[2], sc[0], sc[1], sc[2],
-                     w->keys_in, w->vals_in);
+  PCLMI_HIP(hipMemsetAsync(w->hist, 0, nbins * sizeof(unsigned int), s));
+  const unsigned grid = (unsigned)((nq + 255) / 256);
+  hipLaunchKernelGGL(cell_count_kernel, dim3(grid), dim3(256), 0, s, d_q, (int)q_stride_f, (int)nq,
+                     t->bb_lo[0], t->bb_lo[1], t->bb_lo[2], sc[0], sc[1], sc[2], 30 - bits, w->keys_in, w->hist);
   size_t tmp = w->cap_tmp;
-  PCLMI_HIP(hipcub::DeviceRadixSort::SortPairs(w->sort_tmp, tmp, w->keys_in, w->keys_out, w->vals_in,
-                                               w->vals_out, (int)nq, 0, 30, s));
+  PCLMI_HIP(hipcub::DeviceScan::ExclusiveSum(w->sort_tmp, tmp, w->hist, w->hist, (int)nbins, s));
+  hipLaunchKernelGGL(cell_scatter_kernel, dim3(grid), dim3(256), 0, s, w->keys_in, (int)nq, w->hist,
+                     w->vals_out);
+  PCLMI_HIP(hipGetLastError());
   *d_order = w->vals_out;
   return PCLMI_OK;
 }
@@ -503,9 +701,9 @@ int launch_knn(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, s
   } else if (k_eff <= 4) {
     launch_union<4, 24, 4>(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
   } else if (k_eff <= 8) {
-    launch_union<8, 32, 2>(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
+    launch_union<8, 24, 1>(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
   } else if (k_eff <= 16) {
-    launch_union<16, 40, 2>(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
+    launch_union<16, 32, 1>(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
   } else if (k_eff <= 32) {
     launch_union<32, 64, 1>(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
   } else {

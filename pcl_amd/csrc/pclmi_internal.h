@@ -70,15 +70,16 @@ struct pclmi_tree {
 namespace pclmi {
 
 struct Workspace {
-  // Morton sort scratch
-  uint32_t *keys_in = nullptr, *keys_out = nullptr;
-  int32_t *vals_in = nullptr, *vals_out = nullptr;
-  void *sort_tmp = nullptr;
-  size_t cap_q = 0, cap_tmp = 0;
+  // query-ordering scratch (counting sort by Morton cell)
+  uint32_t *keys_in = nullptr;  // cell id per query
+  int32_t *vals_out = nullptr;  // sorted slot -> query row
+  uint32_t *hist = nullptr;     // per-cell counts / running offsets
+  void *sort_tmp = nullptr;     // hipcub scan temp storage
+  size_t cap_q = 0, cap_bins = 0, cap_tmp = 0;
   // generic scratch (large-k heaps, radius counts, ...)
   void *scratch = nullptr;
   size_t cap_scratch = 0;
-  int ensure_queries(size_t nq);
+  int ensure_queries(size_t nq, size_t nbins);
   int ensure_scratch(size_t bytes);
   void release();
 };

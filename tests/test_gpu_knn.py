@@ -147,3 +147,23 @@ def test_surface_like_and_far_queries(capi, orc):
     q = np.concatenate([pts[::50] + np.float32(0.3), rng.random((500, 3), dtype=np.float32) * 1000 - 300])
     _check(capi, orc, pts, q.astype(np.float32), 16, brute=False)
     _check(capi, orc, pts, q.astype(np.float32), 1, brute=False)
+
+
+def test_partial_wave_and_nan_queries_do_not_walk_the_whole_tree(capi, orc):
+    # regression: lanes past the end / NaN queries once "needed" every box (box distance of NaN is 0)
+    import time
+    pts = util.uniform_cloud(300_000, 31, 0, 1024)
+    q = util.uniform_cloud(10_047, 32, 0, 1024)  # not a multiple of 64
+    q[5] = np.nan
+    q[4000, 1] = np.inf
+    t = capi.Tree(pts)
+    for k in (1, 16):
+        t.knn(q, k)  # warm up
+        t0 = time.time()
+        gi, gd = t.knn(q, k)
+        dt = time.time() - t0
+        good = np.isfinite(q).all(axis=1)
+        oi, od = orc.Tree(pts).knn(q[good], k, nthreads=8)
+        assert np.array_equal(gi[good], oi) and np.array_equal(gd[good], od)
+        assert (gi[~good] == -1).all() and np.isnan(gd[~good]).all()
+        assert dt < 0.05, "k=%d took %.1f ms" % (k, dt * 1e3)
