@@ -222,7 +222,7 @@ int pclmi_knn_dev(const pclmi_tree *t, const float *d_q, size_t nq, size_t q_str
   hipStream_t s = stream ? (hipStream_t)stream : t->stream;
   WsGuard g(t);
   const int32_t *order = nullptr;
-  int rc = launch_morton_order(t, g.w, d_q, nq, q_stride_bytes / 4, s, &order);
+  int rc = launch_morton_order(t, g.w, d_q, nq, q_stride_bytes / 4, nullptr, nullptr, s, &order);
   if (rc) return rc;
   rc = launch_knn(t, g.w, d_q, nq, q_stride_bytes / 4, order, k_eff, d_idx, d_d2, s);
   if (rc) return rc;

@@ -1,0 +1,608 @@
+// api_icp.hip - C ABI: correspondences, rigid-transform estimation, transform, ICP.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <random>
+#include <vector>
+
+#include "pclmi_internal.h"
+
+using namespace pclmi;
+
+namespace {
+
+// minimal RAII device buffer
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  ~DevBuf() { reset(); }
+  void reset() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  int alloc(size_t count) {
+    reset();
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc(&p, count * sizeof(T));
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc", __FILE__, __LINE__);
+    n = count;
+    return PCLMI_OK;
+  }
+};
+
+#define RC(call)              \
+  do {                        \
+    int rc_ = (call);         \
+    if (rc_) return rc_;      \
+  } while (0)
+
+bool is_identity(const float *T) {
+  for (int i = 0; i < 16; ++i)
+    if (T[i] != ((i % 5 == 0) ? 1.f : 0.f)) return false;
+  return true;
+}
+
+void set_identity(float *T) {
+  for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.f : 0.f;
+}
+
+// host points (strided) -> device float4 (x, y, z, 1), optionally through an index list
+int upload_packed(const float *h, size_t n_rows, size_t stride_bytes, const int32_t *rows, size_t n_sel,
+                  DevBuf<float4> &out, hipStream_t s) {
+  const size_t n = rows ? n_sel : n_rows;
+  std::vector<float4> tmp(n ? n : 1);
+  const size_t sf = stride_bytes / 4;
+  for (size_t i = 0; i < n; ++i) {
+    size_t r = rows ? (size_t)rows[i] : i;
+    if (r >= n_rows) {
+      set_error("index %zu out of range (%zu rows)", r, n_rows);
+      return PCLMI_ERR_INVALID;
+    }
+    const float *p = h + r * sf;
+    tmp[i] = make_float4(p[0], p[1], p[2], 1.f);
+  }
+  RC(out.alloc(n));
+  if (n) PCLMI_HIP(hipMemcpyAsync(out.p, tmp.data(), n * sizeof(float4), hipMemcpyHostToDevice, s));
+  PCLMI_HIP(hipStreamSynchronize(s));  // tmp goes out of scope
+  return PCLMI_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+struct pclmi_icp_ctx {
+  const pclmi_tree *tree = nullptr;
+  size_t n = 0;
+  DevBuf<float4> pts;     // source points, Morton-cell order, transformed in place every step
+  DevBuf<int> order;      // slot -> original row
+  DevBuf<int> inv;        // original row -> slot
+  DevBuf<int> nn;         // per slot: index of the nearest target row (-1: not searchable)
+  DevBuf<float> dist;     // per slot: min(d2, thr2) of the previous step (correspondence_distances_)
+  DevBuf<double> partials;
+  DevBuf<double> sums;
+  double origin[3] = {0, 0, 0};
+  bool pending = false;   // a transform waits to be applied by the next step / by end()
+  float T[16];
+  hipStream_t stream = nullptr;
+  double last_thr2 = 0.0;
+};
+
+extern "C" {
+
+int pclmi_transform(float *xyz, size_t n, size_t stride_bytes, const float T[16]) {
+  PCLMI_CHECK(T != nullptr && (n == 0 || xyz != nullptr), PCLMI_ERR_INVALID, "NULL argument");
+  PCLMI_CHECK(stride_bytes >= 12 && stride_bytes % 4 == 0, PCLMI_ERR_INVALID, "bad stride %zu", stride_bytes);
+  PCLMI_CHECK(pclmi_device_count() > 0, PCLMI_ERR_NO_DEVICE, "no HIP device visible: libpclmi has no CPU fallback");
+  if (n == 0) return PCLMI_OK;
+  DevBuf<float4> d;
+  RC(upload_packed(xyz, n, stride_bytes, nullptr, 0, d, nullptr));
+  launch_transform(d.p, n, make_xf(T), nullptr);
+  std::vector<float4> h(n);
+  PCLMI_HIP(hipMemcpy(h.data(), d.p, n * sizeof(float4), hipMemcpyDeviceToHost));
+  const size_t sf = stride_bytes / 4;
+  for (size_t i = 0; i < n; ++i) {
+    xyz[i * sf + 0] = h[i].x;
+    xyz[i * sf + 1] = h[i].y;
+    xyz[i * sf + 2] = h[i].z;
+  }
+  return PCLMI_OK;
+}
+
+int pclmi_estimate_rigid_svd(const float *src, size_t n_src, size_t src_stride_bytes, const int32_t *src_idx,
+                             const float *tgt, size_t n_tgt, size_t tgt_stride_bytes, const int32_t *tgt_idx,
+                             size_t n, float T[16]) {
+  PCLMI_CHECK(src && tgt && T, PCLMI_ERR_INVALID, "NULL argument");
+  PCLMI_CHECK(src_stride_bytes >= 12 && src_stride_bytes % 4 == 0 && tgt_stride_bytes >= 12 &&
+                  tgt_stride_bytes % 4 == 0,
+              PCLMI_ERR_INVALID, "bad stride");
+  PCLMI_CHECK(pclmi_device_count() > 0, PCLMI_ERR_NO_DEVICE, "no HIP device visible: libpclmi has no CPU fallback");
+  set_identity(T);
+  PCLMI_CHECK(n > 0, PCLMI_ERR_NOT_ENOUGH, "no point pairs");
+  PCLMI_CHECK(src_idx || n <= n_src, PCLMI_ERR_INVALID, "n exceeds the source cloud");
+  PCLMI_CHECK(tgt_idx || n <= n_tgt, PCLMI_ERR_INVALID, "n exceeds the target cloud");
+  DevBuf<float4> ds, dt;
+  RC(upload_packed(src, n_src, src_stride_bytes, src_idx, n, ds, nullptr));
+  RC(upload_packed(tgt, n_tgt, tgt_stride_bytes, tgt_idx, n, dt, nullptr));
+  // moments are taken about the first target point (keeps the one-pass sums well conditioned)
+  const float *t0 = tgt + (size_t)(tgt_idx ? tgt_idx[0] : 0) * (tgt_stride_bytes / 4);
+  const double origin[3] = {t0[0], t0[1], t0[2]};
+  DevBuf<double> partials, sums;
+  RC(partials.alloc((size_t)pair_reduce_blocks(n) * PCLMI_ICP_NSUMS));
+  RC(sums.alloc(PCLMI_ICP_NSUMS));
+  launch_pair_reduce(ds.p, nullptr, dt.p, nullptr, nullptr, n, origin, partials.p, sums.p, nullptr);
+  double h[PCLMI_ICP_NSUMS];
+  PCLMI_HIP(hipMemcpy(h, sums.p, sizeof(h), hipMemcpyDeviceToHost));
+  return solve_rigid_from_sums(h, T);
+}
+
+// ---- correspondence estimation -------------------------------------------------------------
+static int nn1_of(const pclmi_tree *tree, const float *pts, size_t n_rows, size_t stride_bytes,
+                  const int32_t *rows, size_t n_sel, std::vector<int32_t> &idx, std::vector<float> &d2) {
+  const size_t n = rows ? n_sel : n_rows;
+  idx.assign(n, -1);
+  d2.assign(n, 0.f);
+  if (n == 0 || tree->n == 0) return PCLMI_OK;
+  DevBuf<float4> d;
+  RC(upload_packed(pts, n_rows, stride_bytes, rows, n_sel, d, nullptr));
+  DevBuf<int> di;
+  DevBuf<float> dd;
+  RC(di.alloc(n));
+  RC(dd.alloc(n));
+  RC(pclmi_knn_dev(tree, (const float *)d.p, n, 16, 1, di.p, dd.p, nullptr));
+  PCLMI_HIP(hipMemcpy(idx.data(), di.p, n * 4, hipMemcpyDeviceToHost));
+  PCLMI_HIP(hipMemcpy(d2.data(), dd.p, n * 4, hipMemcpyDeviceToHost));
+  return PCLMI_OK;
+}
+
+int pclmi_correspondences(const pclmi_tree *target, const float *src, size_t n_src, size_t stride_bytes,
+                          const int32_t *src_indices, size_t n_indices, double max_distance,
+                          pclmi_correspondence *out, size_t *n_out) {
+  PCLMI_CHECK(target && n_out && (out || n_src == 0), PCLMI_ERR_INVALID, "NULL argument");
+  PCLMI_CHECK(n_src == 0 || src, PCLMI_ERR_INVALID, "src is NULL");
+  PCLMI_CHECK(stride_bytes >= 12 && stride_bytes % 4 == 0, PCLMI_ERR_INVALID, "bad stride %zu", stride_bytes);
+  *n_out = 0;
+  std::vector<int32_t> idx;
+  std::vector<float> d2;
+  RC(nn1_of(target, src, n_src, stride_bytes, src_indices, n_indices, idx, d2));
+  const double max2 = max_distance * max_distance;
+  size_t c = 0;
+  for (size_t i = 0; i < idx.size(); ++i) {
+    if (idx[i] < 0) continue;               // empty tree / non-finite query
+    if ((double)d2[i] > max2) continue;     // correspondence_estimation.hpp:108 (non-strict keep)
+    out[c].index_query = src_indices ? src_indices[i] : (int32_t)i;
+    out[c].index_match = idx[i];
+    out[c].distance = d2[i];
+    ++c;
+  }
+  *n_out = c;
+  return PCLMI_OK;
+}
+
+int pclmi_correspondences_reciprocal(const pclmi_tree *target, const pclmi_tree *source_tree, const float *src,
+                                     size_t n_src, size_t src_stride_bytes, const int32_t *src_indices,
+                                     size_t n_indices, const float *tgt, size_t n_tgt, size_t tgt_stride_bytes,
+                                     double max_distance, pclmi_correspondence *out, size_t *n_out) {
+  PCLMI_CHECK(target && source_tree && n_out && tgt, PCLMI_ERR_INVALID, "NULL argument");
+  PCLMI_CHECK(n_src == 0 || (src && out), PCLMI_ERR_INVALID, "src/out is NULL");
+  PCLMI_CHECK(src_stride_bytes >= 12 && src_stride_bytes % 4 == 0 && tgt_stride_bytes >= 12 &&
+                  tgt_stride_bytes % 4 == 0,
+              PCLMI_ERR_INVALID, "bad stride");
+  *n_out = 0;
+  std::vector<int32_t> idx, ridx;
+  std::vector<float> d2, rd2;
+  RC(nn1_of(target, src, n_src, src_stride_bytes, src_indices, n_indices, idx, d2));
+  const double max2 = max_distance * max_distance;
+  // second search: the matched target points back into the source tree (:187)
+  std::vector<int32_t> rows;
+  std::vector<size_t> who;
+  for (size_t i = 0; i < idx.size(); ++i) {
+    if (idx[i] < 0 || (double)d2[i] > max2) continue;
+    PCLMI_CHECK((size_t)idx[i] < n_tgt, PCLMI_ERR_INVALID, "tgt does not match the target tree");
+    rows.push_back(idx[i]);
+    who.push_back(i);
+  }
+  RC(nn1_of(source_tree, tgt, n_tgt, tgt_stride_bytes, rows.data(), rows.size(), ridx, rd2));
+  size_t c = 0;
+  for (size_t a = 0; a < who.size(); ++a) {
+    const size_t i = who[a];
+    const int32_t q = src_indices ? src_indices[i] : (int32_t)i;
+    if (ridx[a] < 0 || (double)rd2[a] > max2 || ridx[a] != q) continue;  // :188
+    out[c].index_query = q;
+    out[c].index_match = idx[i];
+    out[c].distance = d2[i];
+    ++c;
+  }
+  *n_out = c;
+  return PCLMI_OK;
+}
+
+// ---- sharded ICP steps ---------------------------------------------------------------------
+int pclmi_icp_begin(const pclmi_tree *target, const float *src, size_t n_src, size_t stride_bytes,
+                    const float *guess, pclmi_icp_ctx **out) {
+  PCLMI_CHECK(target && out, PCLMI_ERR_INVALID, "NULL argument");
+  *out = nullptr;
+  PCLMI_CHECK(n_src == 0 || src, PCLMI_ERR_INVALID, "src is NULL");
+  PCLMI_CHECK(stride_bytes >= 12 && stride_bytes % 4 == 0, PCLMI_ERR_INVALID, "bad stride %zu", stride_bytes);
+  PCLMI_CHECK(n_src < ((size_t)1 << 31), PCLMI_ERR_UNSUPPORTED, "more than 2^31-1 source points");
+  PCLMI_CHECK(target->n > 0, PCLMI_ERR_INVALID, "the target tree is empty");
+  PCLMI_HIP(hipSetDevice(target->device));
+  pclmi_icp_ctx *c = new pclmi_icp_ctx();
+  c->tree = target;
+  c->n = n_src;
+  c->stream = target->stream;
+  set_identity(c->T);
+  auto fail = [&](int code) {
+    delete c;
+    return code;
+  };
+  int rc;
+  // output <- input with w = 1 (registration.hpp:149-163), then the guess (icp.hpp:60-66)
+  DevBuf<float4> raw;
+  if ((rc = upload_packed(src, n_src, stride_bytes, nullptr, 0, raw, c->stream))) return fail(rc);
+  if (guess && !is_identity(guess)) launch_transform(raw.p, n_src, make_xf(guess), c->stream);
+  // Morton-cell order over the source's own bounding box
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  const size_t sf = stride_bytes / 4;
+  for (size_t i = 0; i < n_src; ++i) {
+    const float *p = src + i * sf;
+    if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2])) continue;
+    float q[3] = {p[0], p[1], p[2]};
+    if (guess && !is_identity(guess))
+      for (int d = 0; d < 3; ++d)
+        q[d] = guess[d * 4 + 0] * p[0] + guess[d * 4 + 1] * p[1] + guess[d * 4 + 2] * p[2] + guess[d * 4 + 3];
+    for (int d = 0; d < 3; ++d) {
+      lo[d] = std::min(lo[d], q[d]);
+      hi[d] = std::max(hi[d], q[d]);
+    }
+  }
+  if (!(lo[0] <= hi[0])) lo[0] = lo[1] = lo[2] = hi[0] = hi[1] = hi[2] = 0.f;
+  if ((rc = c->pts.alloc(n_src)) || (rc = c->order.alloc(n_src)) || (rc = c->inv.alloc(n_src)) ||
+      (rc = c->nn.alloc(n_src)) || (rc = c->dist.alloc(n_src)) ||
+      (rc = c->partials.alloc((size_t)std::max(icp_step_blocks(n_src), pair_reduce_blocks(n_src)) * PCLMI_ICP_NSUMS)) ||
+      (rc = c->sums.alloc(PCLMI_ICP_NSUMS)))
+    return fail(rc);
+  {
+    WsGuard g(target);
+    const int32_t *d_order = nullptr;
+    if ((rc = launch_morton_order(target, g.w, (const float *)raw.p, n_src, 4, lo, hi, c->stream, &d_order)))
+      return fail(rc);
+    if (d_order) {
+      if (hipMemcpyAsync(c->order.p, d_order, n_src * 4, hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
+        return fail(hip_fail(hipGetLastError(), "order copy", __FILE__, __LINE__));
+    } else {
+      launch_iota(c->order.p, n_src, c->stream);
+    }
+    if (hipStreamSynchronize(c->stream) != hipSuccess)
+      return fail(hip_fail(hipGetLastError(), "sync", __FILE__, __LINE__));
+  }
+  launch_permute(raw.p, c->order.p, n_src, c->pts.p, c->stream);
+  // inv[order[slot]] = slot
+  {
+    DevBuf<int> ids;
+    if ((rc = ids.alloc(n_src))) return fail(rc);
+    launch_iota(ids.p, n_src, c->stream);
+    // scatter: reuse unpermute on ints via gather of identity is not possible; do it on the host side of
+    // the API only once per align - cheap relative to the upload
+    std::vector<int> h_order(n_src ? n_src : 1), h_inv(n_src ? n_src : 1);
+    if (n_src && hipMemcpy(h_order.data(), c->order.p, n_src * 4, hipMemcpyDeviceToHost) != hipSuccess)
+      return fail(hip_fail(hipGetLastError(), "order download", __FILE__, __LINE__));
+    for (size_t s = 0; s < n_src; ++s) h_inv[h_order[s]] = (int)s;
+    if (n_src && hipMemcpy(c->inv.p, h_inv.data(), n_src * 4, hipMemcpyHostToDevice) != hipSuccess)
+      return fail(hip_fail(hipGetLastError(), "inv upload", __FILE__, __LINE__));
+  }
+  if (n_src && hipMemsetAsync(c->dist.p, 0, n_src * 4, c->stream) != hipSuccess)  // previous distances start at 0
+    return fail(hip_fail(hipGetLastError(), "memset", __FILE__, __LINE__));
+  // moments are taken about the centre of the target's bounding box: identical on every rank
+  for (int d = 0; d < 3; ++d) c->origin[d] = 0.5 * ((double)target->bb_lo[d] + (double)target->bb_hi[d]);
+  if (hipStreamSynchronize(c->stream) != hipSuccess)
+    return fail(hip_fail(hipGetLastError(), "sync", __FILE__, __LINE__));
+  *out = c;
+  return PCLMI_OK;
+}
+
+int pclmi_icp_step_dev(pclmi_icp_ctx *c, double max_correspondence_distance, double *d_sums, void *stream) {
+  PCLMI_CHECK(c && d_sums, PCLMI_ERR_INVALID, "NULL argument");
+  PCLMI_HIP(hipSetDevice(c->tree->device));
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  const double thr2 = max_correspondence_distance * max_correspondence_distance;  // icp.hpp:57
+  c->last_thr2 = thr2;
+  launch_icp_step(c->tree, c->pts.p, c->n, c->pending, make_xf(c->T), thr2, c->nn.p, c->dist.p, c->origin,
+                  c->partials.p, d_sums, s);
+  c->pending = false;
+  PCLMI_HIP(hipGetLastError());
+  return PCLMI_OK;
+}
+
+int pclmi_icp_step(pclmi_icp_ctx *c, double max_correspondence_distance, double h_sums[PCLMI_ICP_NSUMS]) {
+  PCLMI_CHECK(c && h_sums, PCLMI_ERR_INVALID, "NULL argument");
+  RC(pclmi_icp_step_dev(c, max_correspondence_distance, c->sums.p, nullptr));
+  PCLMI_HIP(hipMemcpyAsync(h_sums, c->sums.p, PCLMI_ICP_NSUMS * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  PCLMI_HIP(hipStreamSynchronize(c->stream));
+  return PCLMI_OK;
+}
+
+int pclmi_icp_set_transform(pclmi_icp_ctx *c, const float T[16]) {
+  PCLMI_CHECK(c && T, PCLMI_ERR_INVALID, "NULL argument");
+  if (c->pending) {  // two transforms without a step in between: apply the first one now
+    PCLMI_HIP(hipSetDevice(c->tree->device));
+    launch_transform(c->pts.p, c->n, make_xf(c->T), c->stream);
+  }
+  std::memcpy(c->T, T, 16 * sizeof(float));
+  c->pending = true;
+  return PCLMI_OK;
+}
+
+int pclmi_icp_end(pclmi_icp_ctx *c, float *aligned) {
+  if (!c) return PCLMI_OK;
+  int rc = PCLMI_OK;
+  (void)hipSetDevice(c->tree->device);
+  if (aligned && c->n) {
+    if (c->pending) launch_transform(c->pts.p, c->n, make_xf(c->T), c->stream);
+    DevBuf<float4> outb;
+    rc = outb.alloc(c->n);
+    if (!rc) {
+      launch_unpermute(c->pts.p, c->order.p, c->n, outb.p, c->stream);
+      hipError_t e = hipMemcpyAsync(aligned, outb.p, c->n * sizeof(float4), hipMemcpyDeviceToHost, c->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+      if (e != hipSuccess) rc = hip_fail(e, "aligned download", __FILE__, __LINE__);
+    }
+  } else {
+    (void)hipStreamSynchronize(c->stream);
+  }
+  delete c;
+  return rc;
+}
+
+// ---- RANSAC rejection as invoked from ICP (icp.hpp:113-150) ------------------------------------
+// Host control flow restates RandomSampleConsensus::computeModel
+// (sample_consensus/include/pcl/sample_consensus/impl/ransac.hpp:44-133) over
+// SampleConsensusModelRegistration; every O(N) pass (moments, countWithinDistance,
+// selectWithinDistance, the refit sums) runs on the GPU.  Returns the number of inliers, or -1 when
+// no model was found (the caller then keeps all pairs, icp.hpp:128-132).
+namespace {
+
+struct RansacScratch {
+  DevBuf<int> ids, pair_src, pair_slot, pair_tgt, num;
+  DevBuf<unsigned char> keep, flags;
+  DevBuf<int> tgt_of_orig;
+  DevBuf<unsigned int> count;
+  DevBuf<float4> six;
+  DevBuf<unsigned char> tmp;
+  size_t tmp_bytes = 0;
+};
+
+int ransac_icp(pclmi_icp_ctx *c, RansacScratch &rs, const pclmi_icp_params *p, int64_t *n_inliers,
+               double sums_out[PCLMI_ICP_NSUMS]) {
+  *n_inliers = -1;
+  const size_t n = c->n;
+  hipStream_t s = c->stream;
+  const float4 *cloud = (const float4 *)c->tree->d_cloud;
+  if (!rs.ids.p) {
+    RC(rs.ids.alloc(n));
+    RC(rs.pair_src.alloc(n));
+    RC(rs.pair_slot.alloc(n));
+    RC(rs.pair_tgt.alloc(n));
+    RC(rs.num.alloc(1));
+    RC(rs.keep.alloc(n));
+    RC(rs.flags.alloc(n));
+    RC(rs.tgt_of_orig.alloc(n));
+    RC(rs.count.alloc(1));
+    RC(rs.six.alloc(6));
+    launch_iota(rs.ids.p, n, s);
+    size_t need = 0;
+    RC(select_flagged(rs.ids.p, rs.keep.p, n, rs.pair_src.p, rs.num.p, nullptr, 0, &need, s));
+    rs.tmp_bytes = need + 256;
+    RC(rs.tmp.alloc(rs.tmp_bytes));
+  }
+  // kept pairs in ORIGINAL source order (the order the reference's index lists have)
+  launch_corr_flags(c->nn.p, c->pts.p, cloud, c->order.p, n, c->last_thr2, rs.tgt_of_orig.p, rs.keep.p, s);
+  RC(select_flagged(rs.ids.p, rs.keep.p, n, rs.pair_src.p, rs.num.p, rs.tmp.p, rs.tmp_bytes, nullptr, s));
+  int cnt = 0;
+  PCLMI_HIP(hipMemcpyAsync(&cnt, rs.num.p, 4, hipMemcpyDeviceToHost, s));
+  PCLMI_HIP(hipStreamSynchronize(s));
+  if (cnt < 3) return PCLMI_OK;  // getSamples clears the selection, computeModel fails (ransac.hpp:72-76)
+  launch_gather_int(c->inv.p, rs.pair_src.p, cnt, rs.pair_slot.p, s);
+  launch_gather_int(rs.tgt_of_orig.p, rs.pair_src.p, cnt, rs.pair_tgt.p, s);
+  // sample_dist_thresh_ (sac_model_registration.h:257-279)
+  double m[PCLMI_ICP_NSUMS];
+  launch_moment_reduce(c->pts.p, rs.pair_slot.p, cnt, c->partials.p, c->sums.p, s);
+  PCLMI_HIP(hipMemcpyAsync(m, c->sums.p, sizeof(m), hipMemcpyDeviceToHost, s));
+  PCLMI_HIP(hipStreamSynchronize(s));
+  const double inv_n = 1.0 / m[9];
+  double a[9];
+  for (int i = 0; i < 9; ++i) a[i] = m[i] * inv_n;
+  const double C00 = a[0] - a[6] * a[6], C01 = a[1] - a[6] * a[7], C02 = a[2] - a[6] * a[8],
+               C11 = a[3] - a[7] * a[7], C12 = a[4] - a[7] * a[8], C22 = a[5] - a[8] * a[8];
+  const double Cm[9] = {C00, C01, C02, C01, C11, C12, C02, C12, C22};
+  double ev[3];
+  sym_eigvals3_f64(Cm, ev);
+  double sthr = 0.0;
+  for (int i = 0; i < 3; ++i) sthr += std::sqrt(ev[i] > 0 ? ev[i] : 0.0);
+  sthr /= 3.0;
+  sthr *= sthr;
+
+  std::mt19937 gen(12345u);  // boost::mt19937 seed 12345 (sac_model.h:95); rnd() == gen() >> 1
+  std::vector<int> shuf(cnt);
+  for (int i = 0; i < cnt; ++i) shuf[i] = i;
+  const double thresh = p->ransac_outlier_threshold * p->ransac_outlier_threshold;
+  int iterations = 0, best = -INT32_MAX;
+  double k = 1.0;
+  unsigned skipped = 0;
+  const unsigned max_skip = (unsigned)p->ransac_iterations * 10u;
+  bool have = false;
+  float Tbest[16];
+  set_identity(Tbest);
+  float4 h6[6];
+  while (iterations < k && skipped < max_skip) {
+    bool good = false;
+    int sel[3] = {0, 0, 0};
+    for (unsigned iter = 0; iter < 1000u && !good; ++iter) {  // max_sample_checks_ (sac_model.h:470)
+      for (int i = 0; i < 3; ++i) {
+        const uint32_t r = (uint32_t)gen() >> 1;
+        std::swap(shuf[i], shuf[i + (int)(r % (uint32_t)(cnt - i))]);  // drawIndexSample (:401-412)
+      }
+      for (int i = 0; i < 3; ++i) sel[i] = shuf[i];
+      launch_gather_points(c->pts.p, rs.pair_slot.p, cloud, rs.pair_tgt.p, sel, rs.six.p, s);
+      PCLMI_HIP(hipMemcpyAsync(h6, rs.six.p, sizeof(h6), hipMemcpyDeviceToHost, s));
+      PCLMI_HIP(hipStreamSynchronize(s));
+      auto sq = [](const float4 &u, const float4 &v) {
+        const float dx = u.x - v.x, dy = u.y - v.y, dz = u.z - v.z;
+        return dx * dx + dy * dy + dz * dz;
+      };
+      good = (double)sq(h6[2], h6[0]) > sthr && (double)sq(h6[4], h6[0]) > sthr &&
+             (double)sq(h6[4], h6[2]) > sthr;  // isSampleGood (sac_model_registration.hpp:47-60)
+    }
+    if (!good) break;
+    // three-point rigid fit (estimateRigidTransformationSVD, sac_model_registration.hpp:257-302)
+    double sm[PCLMI_ICP_NSUMS] = {0};
+    const double o[3] = {h6[1].x, h6[1].y, h6[1].z};
+    for (int i = 0; i < 3; ++i) {
+      const double sx = h6[2 * i].x - o[0], sy = h6[2 * i].y - o[1], sz = h6[2 * i].z - o[2];
+      const double tx = h6[2 * i + 1].x - o[0], ty = h6[2 * i + 1].y - o[1], tz = h6[2 * i + 1].z - o[2];
+      sm[0] += 1;
+      sm[1] += sx; sm[2] += sy; sm[3] += sz;
+      sm[4] += tx; sm[5] += ty; sm[6] += tz;
+      sm[7] += sx * tx; sm[8] += sx * ty; sm[9] += sx * tz;
+      sm[10] += sy * tx; sm[11] += sy * ty; sm[12] += sy * tz;
+      sm[13] += sz * tx; sm[14] += sz * ty; sm[15] += sz * tz;
+      sm[18] += 1;
+      sm[19] += o[0]; sm[20] += o[1]; sm[21] += o[2];
+    }
+    float T[16];
+    if (solve_rigid_from_sums(sm, T) != PCLMI_OK) {
+      ++skipped;
+      continue;
+    }
+    unsigned int inl = 0;
+    launch_count_within(c->pts.p, rs.pair_slot.p, cloud, rs.pair_tgt.p, cnt, make_xf(T), thresh, rs.count.p,
+                        nullptr, s);
+    PCLMI_HIP(hipMemcpyAsync(&inl, rs.count.p, 4, hipMemcpyDeviceToHost, s));
+    PCLMI_HIP(hipStreamSynchronize(s));
+    if ((int)inl > best) {
+      best = (int)inl;
+      have = true;
+      std::memcpy(Tbest, T, sizeof(T));
+      const double w = (double)best / (double)cnt;
+      double p_no = 1.0 - std::pow(w, 3.0);
+      p_no = std::max(std::numeric_limits<double>::epsilon(), p_no);
+      p_no = std::min(1.0 - std::numeric_limits<double>::epsilon(), p_no);
+      k = std::log(1.0 - 0.99) / std::log(p_no);  // ransac.hpp:102-107
+    }
+    ++iterations;
+    if (iterations > p->ransac_iterations) break;
+  }
+  if (!have) return PCLMI_OK;
+  // selectWithinDistance with the best model, then the sums of the inlier pairs
+  unsigned int inl = 0;
+  launch_count_within(c->pts.p, rs.pair_slot.p, cloud, rs.pair_tgt.p, cnt, make_xf(Tbest), thresh, rs.count.p,
+                      rs.flags.p, s);
+  launch_pair_reduce(c->pts.p, rs.pair_slot.p, cloud, rs.pair_tgt.p, rs.flags.p, cnt, c->origin, c->partials.p,
+                     c->sums.p, s);
+  PCLMI_HIP(hipMemcpyAsync(&inl, rs.count.p, 4, hipMemcpyDeviceToHost, s));
+  PCLMI_HIP(hipMemcpyAsync(sums_out, c->sums.p, PCLMI_ICP_NSUMS * sizeof(double), hipMemcpyDeviceToHost, s));
+  PCLMI_HIP(hipStreamSynchronize(s));
+  *n_inliers = inl;
+  return PCLMI_OK;
+}
+
+}  // namespace
+
+int pclmi_icp_align(const pclmi_icp_params *p, const pclmi_tree *target, const float *src, size_t n_src,
+                    size_t stride_bytes, const float *guess, float final_T[16], float *aligned,
+                    pclmi_icp_stats *stats) {
+  PCLMI_CHECK(p && target && final_T, PCLMI_ERR_INVALID, "NULL argument");
+  set_identity(final_T);
+  if (stats) std::memset(stats, 0, sizeof(*stats));
+  PCLMI_CHECK(n_src > 0 && src, PCLMI_ERR_INVALID, "empty source cloud");
+  pclmi_icp_ctx *c = nullptr;
+  RC(pclmi_icp_begin(target, src, n_src, stride_bytes, guess, &c));
+  if (guess && !is_identity(guess)) std::memcpy(final_T, guess, 16 * sizeof(float));  // icp.hpp:63
+  float T[16], Tprev[16];
+  set_identity(T);
+  RansacScratch rs;
+  int rc = PCLMI_OK, iters = 0, converged = 0;
+  double sums[PCLMI_ICP_NSUMS];
+  double fit = 0.0, tdelta = 0.0;
+  int64_t cnt = 0, used = 0;
+  while (!converged) {  // icp.hpp:72
+    std::memcpy(Tprev, T, sizeof(T));
+    if ((rc = pclmi_icp_step(c, p->max_correspondence_distance, sums))) break;
+    cnt = (int64_t)std::llround(sums[0]);
+    if (cnt < p->min_correspondences) {  // icp.hpp:103-108
+      set_error("not enough correspondences (%lld < %d): relax the threshold parameters", (long long)cnt,
+                p->min_correspondences);
+      rc = PCLMI_ERR_NOT_ENOUGH;
+      break;
+    }
+    used = cnt;
+    const double *solve_sums = sums;
+    double rsums[PCLMI_ICP_NSUMS];
+    if (p->ransac_iterations > 0) {  // icp.hpp:113-150
+      int64_t ninl = -1;
+      if ((rc = ransac_icp(c, rs, p, &ninl, rsums))) break;
+      if (ninl >= 0) {
+        used = ninl;
+        solve_sums = rsums;  // pair sums of the inliers only
+      }
+      if (used < p->min_correspondences) {  // icp.hpp:153-159
+        set_error("not enough correspondences after RANSAC (%lld < %d)", (long long)used, p->min_correspondences);
+        rc = PCLMI_ERR_NOT_ENOUGH;
+        break;
+      }
+    }
+    const double n_points = sums[18] > 0 ? sums[18] : (double)c->n;
+    if ((rc = solve_rigid_from_sums(solve_sums, T))) break;   // icp.hpp:171
+    if ((rc = pclmi_icp_set_transform(c, T))) break;    // icp.hpp:174 (applied by the next step / end)
+    mat4_mul_f32(T, final_T, final_T);                  // icp.hpp:177
+    ++iters;
+    tdelta = 0.0;
+    {
+      float fs = 0.f;
+      for (int i = 0; i < 16; ++i) fs += std::fabs(T[i] - Tprev[i]);
+      tdelta = fs;
+    }
+    fit = sums[17] / n_points;  // registration.hpp:60-68
+    if (iters >= p->max_iterations || tdelta < p->transformation_epsilon ||
+        std::fabs(fit) <= p->euclidean_fitness_epsilon)  // icp.hpp:193-196
+      converged = 1;
+  }
+  if (stats) {
+    stats->iterations = iters;
+    stats->converged = converged;
+    stats->last_correspondences = (int)cnt;
+    stats->last_inliers = (int)used;
+    stats->fitness_delta = fit;
+    stats->transform_delta = tdelta;
+  }
+  int rc2 = pclmi_icp_end(c, aligned);
+  return rc ? rc : rc2;
+}
+
+int pclmi_fitness_score(const pclmi_tree *target, const float *src, size_t n_src, size_t stride_bytes,
+                        const float T[16], double max_range, double *score) {
+  PCLMI_CHECK(target && src && T && score, PCLMI_ERR_INVALID, "NULL argument");
+  PCLMI_CHECK(stride_bytes >= 12 && stride_bytes % 4 == 0, PCLMI_ERR_INVALID, "bad stride %zu", stride_bytes);
+  *score = std::numeric_limits<double>::max();
+  if (n_src == 0 || target->n == 0) return PCLMI_OK;
+  PCLMI_HIP(hipSetDevice(target->device));
+  DevBuf<float4> d;
+  RC(upload_packed(src, n_src, stride_bytes, nullptr, 0, d, nullptr));
+  launch_transform(d.p, n_src, make_xf(T), nullptr);  // registration.hpp:78
+  PCLMI_HIP(hipDeviceSynchronize());
+  DevBuf<int> di;
+  DevBuf<float> dd;
+  DevBuf<double> out2;
+  RC(di.alloc(n_src));
+  RC(dd.alloc(n_src));
+  RC(out2.alloc(2));
+  RC(pclmi_knn_dev(target, (const float *)d.p, n_src, 16, 1, di.p, dd.p, nullptr));
+  launch_fitness(dd.p, n_src, max_range, out2.p, nullptr);
+  double h[2];
+  PCLMI_HIP(hipMemcpy(h, out2.p, sizeof(h), hipMemcpyDeviceToHost));
+  if (h[1] > 0) *score = h[0] / h[1];
+  return PCLMI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,428 @@
+// icp_kernels.hip - device side of the ICP correspondence loop on gfx950 (MI355X).
+//
+// One fused kernel per iteration replaces steps A, C (reduction part) and D of
+// pcl::IterativeClosestPoint::computeTransformation
+// (registration/include/pcl/registration/impl/icp.hpp:84-102,171-174):
+//   p <- T_prev * p (the transform estimated by the previous iteration, transforms.hpp:184-191),
+//   1-NN of p in the target tree (wave-uniform traversal, traverse.hpp),
+//   threshold test d2 < thr2 (strict, icp.hpp:93), d_cur = min(d2, thr2) (icp.hpp:101),
+//   fp64 partial sums of n, sum s, sum t, sum s t' (the inputs of
+//   TransformationEstimationSVD, impl/transformation_estimation_svd.hpp:114-168) reduced with
+//   wavefront shuffles, then an LDS tree per block, then a fixed-order pass over block partials
+//   (bit-reproducible; no float atomics).
+// Source points live on the device in Morton-cell order, so the 64 queries of a wave are
+// neighbours and the loads/stores of the point array are fully coalesced.
+#include <hipcub/hipcub.hpp>
+
+#include "pclmi_internal.h"
+#include "traverse.hpp"
+
+namespace pclmi {
+using namespace dev;
+
+namespace {
+
+__device__ __forceinline__ float4 apply_xf(const Xf &T, float4 p) {
+  // rot * p + trans, one rounding per operation, Eigen's column-sum order
+  // ((c0*x + c1*y) + c2*z) + t  (common/include/pcl/common/impl/transforms.hpp:184-191)
+  float4 o;
+  o.x = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T.m[0], p.x), __fmul_rn(T.m[1], p.y)), __fmul_rn(T.m[2], p.z)), T.m[3]);
+  o.y = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T.m[4], p.x), __fmul_rn(T.m[5], p.y)), __fmul_rn(T.m[6], p.z)), T.m[7]);
+  o.z = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T.m[8], p.x), __fmul_rn(T.m[9], p.y)), __fmul_rn(T.m[10], p.z)), T.m[11]);
+  o.w = p.w;
+  return o;
+}
+
+__device__ __forceinline__ bool finite3(float4 p) { return isfinite(p.x) && isfinite(p.y) && isfinite(p.z); }
+
+__global__ void transform_kernel(float4 *__restrict__ pts, int n, Xf T) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 p = pts[i];
+  if (finite3(p)) pts[i] = apply_xf(T, p);  // the !is_dense branch skips non-finite points (:196-204)
+}
+
+// strided host-layout points -> float4 (x, y, z, 1), optionally through an index list
+__global__ void pack_kernel(const float *__restrict__ in, int stride_f, const int *__restrict__ rows, int n,
+                            float4 *__restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float *p = in + (size_t)(rows ? rows[i] : i) * stride_f;
+  out[i] = make_float4(p[0], p[1], p[2], 1.f);
+}
+
+__global__ void permute_kernel(const float4 *__restrict__ in, const int *__restrict__ order, int n,
+                               float4 *__restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[order[i]];
+}
+
+__global__ void unpermute_kernel(const float4 *__restrict__ in, const int *__restrict__ order, int n,
+                                 float4 *__restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[order[i]] = in[i];
+}
+
+template <typename T>
+__global__ void unpermute_scalar_kernel(const T *__restrict__ in, const int *__restrict__ order, int n,
+                                        T *__restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[order[i]] = in[i];
+}
+
+// wave shuffle reduction of NV doubles, then one LDS row per wave, then thread j sums row entries j
+template <int NV, int WPB>
+__device__ __forceinline__ void block_reduce_store(double (&acc)[NV], double (*lds)[NV], int lane, int wib,
+                                                   double *__restrict__ partial_row) {
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    double v = acc[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    acc[j] = v;
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) lds[wib][j] = acc[j];
+  }
+  __syncthreads();
+  const int tid = threadIdx.x;
+  if (tid < NV) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < WPB; ++w) s += lds[w][tid];
+    partial_row[tid] = s;
+  }
+}
+
+constexpr int NS = PCLMI_ICP_NSUMS;  // 24
+constexpr int ICP_WPB = 4;
+
+// One ICP iteration over the (Morton-ordered) source points.  See file header.
+__global__ __launch_bounds__(64 * ICP_WPB) void icp_step_kernel(TreeView t, float4 *__restrict__ pts, int n,
+                                                                 int apply, Xf T, float thr2f, double thr2,
+                                                                 const float4 *__restrict__ cloud,
+                                                                 int *__restrict__ nn_idx,
+                                                                 float *__restrict__ dist, double ox, double oy,
+                                                                 double oz, double *__restrict__ partials) {
+  __shared__ double lds[ICP_WPB][NS];
+  const int lane = threadIdx.x & 63;
+  const int wib = threadIdx.x >> 6;
+  const int per = (gridDim.x + 7) >> 3;
+  const int blk = (blockIdx.x & 7) * per + (blockIdx.x >> 3);  // XCD-contiguous chunks (speed only)
+  const int slot = (blk * ICP_WPB + wib) * 64 + lane;
+  const bool wave_live = __builtin_amdgcn_readfirstlane(slot) < n;
+  double acc[NS];
+#pragma unroll
+  for (int j = 0; j < NS; ++j) acc[j] = 0.0;
+  if (wave_live) {
+    const bool alive = slot < n;
+    float4 p = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), 1.f);
+    if (alive) {
+      p = pts[slot];
+      if (apply && finite3(p)) {
+        p = apply_xf(T, p);
+        pts[slot] = p;
+      }
+    }
+    const bool searchable = alive && finite3(p);
+    if (!searchable) p.x = p.y = p.z = __builtin_nanf("");
+    const unsigned long long best = wave_nearest(t, p.x, p.y, p.z, searchable, lane);
+    if (alive) {
+      const int idx = searchable ? (int)(unsigned int)(best & 0xffffffffull) : -1;
+      const float d = searchable ? __uint_as_float((unsigned int)(best >> 32)) : __builtin_nanf("");
+      nn_idx[slot] = idx;
+      if (searchable) {
+        const float dc = fminf(d, thr2f);  // icp.hpp:101
+        const float prev = dist[slot];
+        dist[slot] = dc;
+        acc[16] = (double)dc;
+        acc[17] = (double)dc - (double)prev;
+        acc[18] = 1.0;
+        acc[19] = ox;
+        acc[20] = oy;
+        acc[21] = oz;
+        if ((double)d < thr2) {  // strict, icp.hpp:93
+          const float4 q = cloud[idx];
+          const double sx = (double)p.x - ox, sy = (double)p.y - oy, sz = (double)p.z - oz;
+          const double tx = (double)q.x - ox, ty = (double)q.y - oy, tz = (double)q.z - oz;
+          acc[0] = 1.0;
+          acc[1] = sx; acc[2] = sy; acc[3] = sz;
+          acc[4] = tx; acc[5] = ty; acc[6] = tz;
+          acc[7] = sx * tx; acc[8] = sx * ty; acc[9] = sx * tz;
+          acc[10] = sy * tx; acc[11] = sy * ty; acc[12] = sy * tz;
+          acc[13] = sz * tx; acc[14] = sz * ty; acc[15] = sz * tz;
+        }
+      }
+    }
+  }
+  block_reduce_store<NS, ICP_WPB>(acc, lds, lane, wib, partials + (size_t)blockIdx.x * NS);
+}
+
+// fixed-order sum of the block partials: block j of the grid produces out[j]
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const double *__restrict__ partials, int nrows,
+                                                              int nv, double *__restrict__ out) {
+  __shared__ double sh[256];
+  const int j = blockIdx.x;
+  double s = 0.0;
+  for (int r = threadIdx.x; r < nrows; r += 256) s += partials[(size_t)r * nv + j];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[j] = sh[0];
+}
+
+// sums over explicitly paired points (TransformationEstimationSVD on a correspondence list,
+// impl/transformation_estimation_svd.hpp:101-111; also the RANSAC inlier refit)
+constexpr int PR_WPB = 4;
+__global__ __launch_bounds__(64 * PR_WPB) void pair_reduce_kernel(const float4 *__restrict__ src,
+                                                                   const int *__restrict__ sidx,
+                                                                   const float4 *__restrict__ tgt,
+                                                                   const int *__restrict__ tidx,
+                                                                   const unsigned char *__restrict__ flags, int n,
+                                                                   double ox, double oy, double oz,
+                                                                   double *__restrict__ partials) {
+  __shared__ double lds[PR_WPB][NS];
+  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  double acc[NS];
+#pragma unroll
+  for (int j = 0; j < NS; ++j) acc[j] = 0.0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    if (flags && !flags[i]) continue;
+    const float4 p = src[sidx ? sidx[i] : i];
+    const float4 q = tgt[tidx ? tidx[i] : i];
+    const double sx = (double)p.x - ox, sy = (double)p.y - oy, sz = (double)p.z - oz;
+    const double tx = (double)q.x - ox, ty = (double)q.y - oy, tz = (double)q.z - oz;
+    acc[0] += 1.0;
+    acc[1] += sx; acc[2] += sy; acc[3] += sz;
+    acc[4] += tx; acc[5] += ty; acc[6] += tz;
+    acc[7] += sx * tx; acc[8] += sx * ty; acc[9] += sx * tz;
+    acc[10] += sy * tx; acc[11] += sy * ty; acc[12] += sy * tz;
+    acc[13] += sz * tx; acc[14] += sz * ty; acc[15] += sz * tz;
+    acc[18] += 1.0;
+    acc[19] += ox; acc[20] += oy; acc[21] += oz;
+  }
+  block_reduce_store<NS, PR_WPB>(acc, lds, lane, wib, partials + (size_t)blockIdx.x * NS);
+}
+
+// RANSAC support -------------------------------------------------------------------------------
+// countWithinDistance / selectWithinDistance (sample_consensus/.../impl/sac_model_registration.hpp
+// :131-224): pairs with |T s - t|^2 < thr2 in fp32.  flags (nullable) receives 0/1 per pair.
+__global__ __launch_bounds__(256) void count_within_kernel(const float4 *__restrict__ src,
+                                                           const int *__restrict__ sidx,
+                                                           const float4 *__restrict__ tgt,
+                                                           const int *__restrict__ tidx, int n, Xf T, double thr2,
+                                                           unsigned int *__restrict__ count,
+                                                           unsigned char *__restrict__ flags) {
+  int c = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float4 p = apply_xf(T, src[sidx[i]]);
+    const float4 q = tgt[tidx[i]];
+    const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
+    const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+    const bool in = (double)d < thr2;
+    c += in ? 1 : 0;
+    if (flags) flags[i] = in ? 1 : 0;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, (unsigned int)c);
+}
+
+// fp32 second moments of the source points of the pair list (computeMeanAndCovarianceMatrix,
+// common/include/pcl/common/impl/centroid.hpp:553-617), accumulated in fp64
+__global__ __launch_bounds__(64 * PR_WPB) void moment_reduce_kernel(const float4 *__restrict__ src,
+                                                                     const int *__restrict__ sidx, int n,
+                                                                     double *__restrict__ partials) {
+  __shared__ double lds[PR_WPB][NS];
+  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  double acc[NS];
+#pragma unroll
+  for (int j = 0; j < NS; ++j) acc[j] = 0.0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float4 p = src[sidx[i]];
+    const double x = p.x, y = p.y, z = p.z;
+    acc[0] += x * x; acc[1] += x * y; acc[2] += x * z;
+    acc[3] += y * y; acc[4] += y * z; acc[5] += z * z;
+    acc[6] += x; acc[7] += y; acc[8] += z;
+    acc[9] += 1.0;
+  }
+  block_reduce_store<NS, PR_WPB>(acc, lds, lane, wib, partials + (size_t)blockIdx.x * NS);
+}
+
+// correspondences of the last step in ORIGINAL source order: keep[orig] = d2 < thr2
+__global__ void corr_flags_kernel(const int *__restrict__ nn_idx, const float4 *__restrict__ pts,
+                                  const float4 *__restrict__ cloud, const int *__restrict__ order, int n,
+                                  double thr2, int *__restrict__ tgt_of_orig, unsigned char *__restrict__ keep) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int o = order[i];
+  const int j = nn_idx[i];
+  bool k = false;
+  if (j >= 0) {
+    const float4 p = pts[i], q = cloud[j];
+    const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
+    const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+    k = (double)d < thr2;
+  }
+  tgt_of_orig[o] = j;
+  keep[o] = k ? 1 : 0;
+}
+
+__global__ void iota_kernel(int *__restrict__ v, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = i;
+}
+
+__global__ void gather_int_kernel(const int *__restrict__ in, const int *__restrict__ idx, int n,
+                                  int *__restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[idx[i]];
+}
+
+struct Pos3 {
+  int p[3];
+};
+// the three sampled pairs of a RANSAC trial: out[2i] = source point, out[2i+1] = its target point
+__global__ void gather_points_kernel(const float4 *__restrict__ a, const int *__restrict__ ia,
+                                     const float4 *__restrict__ b, const int *__restrict__ ib, Pos3 pos,
+                                     float4 *__restrict__ out) {
+  int i = threadIdx.x;
+  if (i < 3) {
+    out[2 * i] = a[ia[pos.p[i]]];
+    out[2 * i + 1] = b[ib[pos.p[i]]];
+  }
+}
+
+// Registration::getFitnessScore (registration.hpp:83-103): sum / count of d2 <= max_range
+__global__ __launch_bounds__(256) void fitness_kernel(const float *__restrict__ d2, int n, double max_range,
+                                                      double *__restrict__ out /* [2] */) {
+  double s = 0.0, c = 0.0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float d = d2[i];
+    if (d == d && !((double)d > max_range)) {  // registration.hpp:94 skips d > max_range
+      s += fabs((double)d);
+      c += 1.0;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o);
+    c += __shfl_xor(c, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&out[0], s);
+    atomicAdd(&out[1], c);
+  }
+}
+
+inline unsigned blocks_for(size_t n, unsigned per) { return (unsigned)((n + per - 1) / per); }
+
+}  // namespace
+
+// ---- launchers ---------------------------------------------------------------------------------
+void launch_transform(float4 *d_pts, size_t n, const Xf &T, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(transform_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, d_pts, (int)n, T);
+}
+
+void launch_pack(const float *d_in, size_t stride_f, const int *d_rows, size_t n, float4 *d_out, hipStream_t s) {
+  if (n)
+    hipLaunchKernelGGL(pack_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, d_in, (int)stride_f, d_rows, (int)n,
+                       d_out);
+}
+
+void launch_permute(const float4 *in, const int *order, size_t n, float4 *out, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(permute_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, in, order, (int)n, out);
+}
+
+void launch_unpermute(const float4 *in, const int *order, size_t n, float4 *out, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(unpermute_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, in, order, (int)n, out);
+}
+
+unsigned icp_step_blocks(size_t n) {
+  unsigned waves = (unsigned)((n + 63) / 64);
+  unsigned blocks = (waves + ICP_WPB - 1) / ICP_WPB;
+  return (blocks + 7) & ~7u;
+}
+
+void launch_icp_step(const pclmi_tree *t, float4 *d_pts, size_t n, bool apply, const Xf &T, double thr2,
+                     int *d_nn, float *d_dist, const double origin[3], double *d_partials, double *d_sums,
+                     hipStream_t s) {
+  const unsigned blocks = icp_step_blocks(n);
+  hipLaunchKernelGGL(icp_step_kernel, dim3(blocks), dim3(64 * ICP_WPB), 0, s, t->view(), d_pts, (int)n,
+                     apply ? 1 : 0, T, (float)thr2, thr2, (const float4 *)t->d_cloud, d_nn, d_dist, origin[0],
+                     origin[1], origin[2], d_partials);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(NS), dim3(256), 0, s, d_partials, (int)blocks, NS, d_sums);
+}
+
+unsigned pair_reduce_blocks(size_t n) {
+  unsigned b = blocks_for(n, 64 * PR_WPB);
+  return b < 1 ? 1 : (b > 2048 ? 2048 : b);
+}
+
+void launch_pair_reduce(const float4 *src, const int *sidx, const float4 *tgt, const int *tidx,
+                        const unsigned char *flags, size_t n, const double origin[3], double *d_partials,
+                        double *d_sums, hipStream_t s) {
+  const unsigned blocks = pair_reduce_blocks(n);
+  hipLaunchKernelGGL(pair_reduce_kernel, dim3(blocks), dim3(64 * PR_WPB), 0, s, src, sidx, tgt, tidx, flags, (int)n,
+                     origin[0], origin[1], origin[2], d_partials);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(NS), dim3(256), 0, s, d_partials, (int)blocks, NS, d_sums);
+}
+
+void launch_moment_reduce(const float4 *src, const int *sidx, size_t n, double *d_partials, double *d_sums,
+                          hipStream_t s) {
+  const unsigned blocks = pair_reduce_blocks(n);
+  hipLaunchKernelGGL(moment_reduce_kernel, dim3(blocks), dim3(64 * PR_WPB), 0, s, src, sidx, (int)n, d_partials);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(NS), dim3(256), 0, s, d_partials, (int)blocks, NS, d_sums);
+}
+
+void launch_count_within(const float4 *src, const int *sidx, const float4 *tgt, const int *tidx, size_t n,
+                         const Xf &T, double thr2, unsigned int *d_count, unsigned char *d_flags, hipStream_t s) {
+  (void)hipMemsetAsync(d_count, 0, sizeof(unsigned int), s);
+  unsigned b = blocks_for(n, 256);
+  b = b < 1 ? 1 : (b > 4096 ? 4096 : b);
+  hipLaunchKernelGGL(count_within_kernel, dim3(b), dim3(256), 0, s, src, sidx, tgt, tidx, (int)n, T, thr2, d_count,
+                     d_flags);
+}
+
+void launch_corr_flags(const int *d_nn, const float4 *d_pts, const float4 *d_cloud, const int *d_order, size_t n,
+                       double thr2, int *d_tgt_of_orig, unsigned char *d_keep, hipStream_t s) {
+  if (n)
+    hipLaunchKernelGGL(corr_flags_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, d_nn, d_pts, d_cloud, d_order,
+                       (int)n, thr2, d_tgt_of_orig, d_keep);
+}
+
+void launch_iota(int *v, size_t n, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(iota_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, v, (int)n);
+}
+
+void launch_gather_int(const int *in, const int *idx, size_t n, int *out, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(gather_int_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, in, idx, (int)n, out);
+}
+
+void launch_gather_points(const float4 *a, const int *ia, const float4 *b, const int *ib, const int pos[3],
+                          float4 *out, hipStream_t s) {
+  Pos3 p3{{pos[0], pos[1], pos[2]}};
+  hipLaunchKernelGGL(gather_points_kernel, dim3(1), dim3(64), 0, s, a, ia, b, ib, p3, out);
+}
+
+int select_flagged(const int *d_in, const unsigned char *d_flags, size_t n, int *d_out, int *d_num, void *d_tmp,
+                   size_t tmp_bytes, size_t *need, hipStream_t s) {
+  size_t bytes = tmp_bytes;
+  hipError_t e = hipcub::DeviceSelect::Flagged(d_tmp, bytes, d_in, d_flags, d_out, d_num, (int)n, s);
+  if (need) *need = bytes;
+  if (e != hipSuccess) return hip_fail(e, "DeviceSelect::Flagged", __FILE__, __LINE__);
+  return PCLMI_OK;
+}
+
+void launch_fitness(const float *d_d2, size_t n, double max_range, double *d_out2, hipStream_t s) {
+  (void)hipMemsetAsync(d_out2, 0, 2 * sizeof(double), s);
+  unsigned b = blocks_for(n, 256);
+  b = b < 1 ? 1 : (b > 2048 ? 2048 : b);
+  hipLaunchKernelGGL(fitness_kernel, dim3(b), dim3(256), 0, s, d_d2, (int)n, max_range, d_out2);
+}
+
+}  // namespace pclmi

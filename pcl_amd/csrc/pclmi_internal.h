@@ -104,11 +104,55 @@ struct HostTree {
 void build_host_tree(const float *pts, const int32_t *ext, size_t n, HostTree *out);
 
 // ---- kernels launchers (knn_kernels.hip) -------------------------------------------------
-// order: nullable device permutation (sorted slot -> query row)
+// order: nullable device permutation (sorted slot -> query row).  bb_lo / bb_hi: box the Morton
+// cells are laid over (NULL = the tree's bounding box).
 int launch_morton_order(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq,
-                        size_t q_stride_f, hipStream_t s, const int32_t **d_order);
+                        size_t q_stride_f, const float *bb_lo, const float *bb_hi, hipStream_t s,
+                        const int32_t **d_order);
 int launch_knn(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, size_t q_stride_f,
                const int32_t *d_order, int k_eff, int32_t *d_idx, float *d_d2, hipStream_t s);
+
+
+// ---- ICP / registration kernels (icp_kernels.hip) -----------------------------------------
+struct Xf {
+  float m[12];  // rows 0..2 of a row-major 4x4
+};
+inline Xf make_xf(const float T[16]) {
+  Xf x;
+  for (int i = 0; i < 12; ++i) x.m[i] = T[i];
+  return x;
+}
+void launch_transform(float4 *d_pts, size_t n, const Xf &T, hipStream_t s);
+void launch_pack(const float *d_in, size_t stride_f, const int *d_rows, size_t n, float4 *d_out, hipStream_t s);
+void launch_permute(const float4 *in, const int *order, size_t n, float4 *out, hipStream_t s);
+void launch_unpermute(const float4 *in, const int *order, size_t n, float4 *out, hipStream_t s);
+unsigned icp_step_blocks(size_t n);
+void launch_icp_step(const pclmi_tree *t, float4 *d_pts, size_t n, bool apply, const Xf &T, double thr2,
+                     int *d_nn, float *d_dist, const double origin[3], double *d_partials, double *d_sums,
+                     hipStream_t s);
+unsigned pair_reduce_blocks(size_t n);
+void launch_pair_reduce(const float4 *src, const int *sidx, const float4 *tgt, const int *tidx,
+                        const unsigned char *flags, size_t n, const double origin[3], double *d_partials,
+                        double *d_sums, hipStream_t s);
+void launch_moment_reduce(const float4 *src, const int *sidx, size_t n, double *d_partials, double *d_sums,
+                          hipStream_t s);
+void launch_count_within(const float4 *src, const int *sidx, const float4 *tgt, const int *tidx, size_t n,
+                         const Xf &T, double thr2, unsigned int *d_count, unsigned char *d_flags, hipStream_t s);
+void launch_corr_flags(const int *d_nn, const float4 *d_pts, const float4 *d_cloud, const int *d_order, size_t n,
+                       double thr2, int *d_tgt_of_orig, unsigned char *d_keep, hipStream_t s);
+void launch_iota(int *v, size_t n, hipStream_t s);
+void launch_gather_int(const int *in, const int *idx, size_t n, int *out, hipStream_t s);
+void launch_gather_points(const float4 *a, const int *ia, const float4 *b, const int *ib, const int pos[3],
+                          float4 *out, hipStream_t s);
+int select_flagged(const int *d_in, const unsigned char *d_flags, size_t n, int *d_out, int *d_num, void *d_tmp,
+                   size_t tmp_bytes, size_t *need, hipStream_t s);
+void launch_fitness(const float *d_d2, size_t n, double max_range, double *d_out2, hipStream_t s);
+
+// ---- host math (registration_host.cpp; needs no GPU) ----------------------------------------
+void svd3_f64(const double A[9], double U[9], double S[3], double V[9]);
+int solve_rigid_from_sums(const double sums[PCLMI_ICP_NSUMS], float T[16]);
+void mat4_mul_f32(const float A[16], const float B[16], float C[16]);
+void sym_eigvals3_f64(const double M[9], double ev[3]);
 
 }  // namespace pclmi
 #endif

@@ -1,0 +1,281 @@
+// traverse.hpp - device-side building blocks of the wave-uniform ("union") tree traversal,
+// shared by the kNN, radius and ICP kernels.  gfx950 / wave64 only.
+#ifndef PCLMI_TRAVERSE_HPP_
+#define PCLMI_TRAVERSE_HPP_
+
+#include "pclmi_internal.h"
+
+namespace pclmi {
+namespace dev {
+
+// Uniform (scalar) loads: reading through the constant address space with a wave-uniform
+// address makes hipcc emit s_load_dwordx8 / x16 into SGPRs instead of per-lane vector loads.
+typedef float f8v __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef const f8v __attribute__((address_space(4))) *cbox_ptr;    // one node box (32 B)
+typedef const f16v __attribute__((address_space(4))) *cgrp_ptr;   // 64-byte line
+
+constexpr int L = kLeafSize;
+constexpr int G = L / 4;
+
+#ifdef PCLMI_STATS
+// development statistics (never compiled into the shipped library)
+#ifdef PCLMI_STATS_OWNER
+__device__ unsigned long long g_stats[16];
+#else
+extern __device__ unsigned long long g_stats[16];
+#endif
+#define STAT_DECL unsigned long long sacc_[16] = {0}
+#define STAT_ADD(i, v) do { sacc_[i] += (unsigned long long)(v); } while (0)
+#define STAT_FLUSH do { if (lane == 0) { _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&g_stats[i_], sacc_[i_]); } } while (0)
+// cycle stamps: one statement = s_memtime + its wait, fenced for the scheduler (diagnostic build only)
+#define STAMP(var) unsigned long long var; __builtin_amdgcn_sched_barrier(0); \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0)
+#define STAMP_ACC(i, t1, t0) STAT_ADD(i, (t1) - (t0))
+#else
+#define STAT_DECL do { } while (0)
+#define STAT_FLUSH do { } while (0)
+#define STAT_ADD(i, v) do { } while (0)
+#define STAMP(var) do { } while (0)
+#define STAMP_ACC(i, t1, t0) do { } while (0)
+#endif  // point groups per bucket: [x0..3 | y0..3 | z0..3 | idx0..3]
+
+__device__ __forceinline__ float sq3(float dx, float dy, float dz) {
+  // one rounding per operation, fixed order: ((dx*dx + dy*dy) + dz*dz)
+  return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+// squared distance from q to an axis-aligned box given as 8 uniform floats.  Uses the same
+// operation order as sq3, so it is a true lower bound (in fp32) of sq3 to any point inside.
+__device__ __forceinline__ float box_dist(float qx, float qy, float qz, float lx, float ly, float lz,
+                                          float hx, float hy, float hz) {
+  float dx = fmaxf(fmaxf(lx - qx, qx - hx), 0.f);
+  float dy = fmaxf(fmaxf(ly - qy, qy - hy), 0.f);
+  float dz = fmaxf(fmaxf(lz - qz, qz - hz), 0.f);
+  return sq3(dx, dy, dz);
+}
+
+// Packed fp32 (v_pk_add_f32 / v_pk_mul_f32): two candidates or two boxes per instruction.  Each
+// half is an ordinary IEEE fp32 operation, so results are bit-identical to sq3 / box_dist.
+typedef float f2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f2v sq3_pk(f2v dx, f2v dy, f2v dz) {
+#pragma clang fp contract(off)
+  const f2v xx = dx * dx, yy = dy * dy, zz = dz * dz;
+  const f2v s = xx + yy;
+  return s + zz;
+}
+
+__device__ __forceinline__ f2v box_dist_pk(f2v qx, f2v qy, f2v qz, f2v lx, f2v ly, f2v lz, f2v hx, f2v hy,
+                                           f2v hz) {
+#pragma clang fp contract(off)
+  const f2v ax = lx - qx, bx = qx - hx;
+  const f2v ay = ly - qy, by = qy - hy;
+  const f2v az = lz - qz, bz = qz - hz;
+  f2v dx, dy, dz;
+  dx.x = fmaxf(fmaxf(ax.x, bx.x), 0.f);
+  dx.y = fmaxf(fmaxf(ax.y, bx.y), 0.f);
+  dy.x = fmaxf(fmaxf(ay.x, by.x), 0.f);
+  dy.y = fmaxf(fmaxf(ay.y, by.y), 0.f);
+  dz.x = fmaxf(fmaxf(az.x, bz.x), 0.f);
+  dz.y = fmaxf(fmaxf(az.y, bz.y), 0.f);
+  return sq3_pk(dx, dy, dz);
+}
+
+__device__ __forceinline__ unsigned long long make_key(float d, int i) {
+  return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)i;
+}
+
+template <int K>
+__device__ __forceinline__ void list_insert(float (&a)[K], float d) {
+  // a ascending.  new a[j] = median(a[j-1], a[j], d); new a[0] = min(a[0], d).
+#pragma unroll
+  for (int j = K - 1; j >= 1; --j) a[j] = __builtin_amdgcn_fmed3f(a[j - 1], a[j], d);
+  a[0] = fminf(a[0], d);
+}
+
+// wave-uniform stack kept in the lanes of one VGPR
+struct LaneStack {
+  int v;
+  int sp;
+  int lane;
+  __device__ __forceinline__ void push(int node) {
+    v = (lane == sp) ? node : v;
+    ++sp;
+  }
+  __device__ __forceinline__ int pop() {
+    --sp;
+    return __builtin_amdgcn_readlane(v, sp);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Shared prologue: XCD-aware wave -> query-chunk assignment and query load.
+struct LaneQuery {
+  float x, y, z;
+  int qi;
+  bool alive;       // lane maps to a query row
+  bool searchable;  // ... and that query is finite
+};
+
+template <int WPB>
+__device__ __forceinline__ bool load_lane_query(const float *__restrict__ q, int q_stride_f,
+                                                const int *__restrict__ order, int nq, LaneQuery &o) {
+  const int lane = threadIdx.x & 63;
+  const int wib = threadIdx.x >> 6;
+  // blocks b, b+8, b+16 ... share an XCD (and its L2): give each XCD one contiguous range of the
+  // sorted queries so that its L2 holds one part of the tree.  (Placement only affects speed.)
+  const int per = (gridDim.x + 7) >> 3;
+  const int blk = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  const int slot = (blk * WPB + wib) * 64 + lane;
+  if (__builtin_amdgcn_readfirstlane(slot) >= nq) return false;  // whole wave past the end
+  o.alive = slot < nq;
+  o.qi = o.alive ? (order ? order[slot] : slot) : 0;
+  o.x = o.y = o.z = __builtin_nanf("");  // dead lanes: every comparison is false
+  if (o.alive) {
+    const float *p = q + (size_t)o.qi * q_stride_f;
+    o.x = p[0];
+    o.y = p[1];
+    o.z = p[2];
+  }
+  // Lanes past the end and non-finite queries must never steer the wave: their coordinates are
+  // NaN (no candidate ever passes) and the callers give them a NEGATIVE bound, because
+  // box_dist(NaN) is 0 (fmax drops NaNs) and would otherwise "need" every box of the tree.
+  o.searchable = o.alive && isfinite(o.x) && isfinite(o.y) && isfinite(o.z);
+  if (!o.searchable) o.x = o.y = o.z = __builtin_nanf("");
+  return true;
+}
+
+// Per-lane pre-pass: walk down to a nearby bucket (towards the nearer child box), scan it and its
+// sibling bucket with ordinary vector loads, and return the K-th smallest distance found.  This
+// is only an UPPER BOUND on the true K-th distance (FLT_MAX when fewer than K points were seen);
+// starting the union traversal with it prunes the far subtrees from the first step on.
+template <int K>
+__device__ __forceinline__ float lane_bound(const TreeView &t, float qx, float qy, float qz) {
+  const int M = t.M;
+  int node = 1;
+  while (node < M) {
+    const float4 *b = reinterpret_cast<const float4 *>(t.box + (size_t)node * 16);
+    const float4 b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
+    const float m0 = box_dist(qx, qy, qz, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y);
+    const float m1 = box_dist(qx, qy, qz, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y);
+    node = 2 * node + (m1 < m0 ? 1 : 0);
+  }
+  float a[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) a[j] = 3.402823466e+38f;
+  // scan the NB sibling buckets around the one reached (>= 2K points when they are all full)
+  constexpr int NB = (2 * K / L) > 2 ? (2 * K / L) : 2;
+  const int first = node & ~(NB - 1);
+#pragma unroll 1
+  for (int s = 0; s < NB; ++s) {
+    const int bn = first + s;
+    if (bn < M || bn > 2 * M - 1) continue;
+    const float4 *rec = reinterpret_cast<const float4 *>(t.leaf + (size_t)(bn - M) * (4 * L));
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const float4 X = rec[g * 4 + 0], Y = rec[g * 4 + 1], Z = rec[g * 4 + 2];
+      list_insert<K>(a, sq3(qx - X.x, qy - Y.x, qz - Z.x));
+      list_insert<K>(a, sq3(qx - X.y, qy - Y.y, qz - Z.y));
+      list_insert<K>(a, sq3(qx - X.z, qy - Y.z, qz - Z.z));
+      list_insert<K>(a, sq3(qx - X.w, qy - Y.w, qz - Z.w));
+    }
+  }
+  return a[K - 1];
+}
+
+// One step of the wave-uniform traversal at inner node `node`: tests the 4 grandchildren at once
+// when both children are inner nodes (their boxes are two adjacent 64-byte lines), else the 2
+// children; pushes the boxes some lane still needs, nearest (by lane majority) on top.
+__device__ __forceinline__ void expand_inner(LaneStack &st, const cgrp_ptr box2, int node, int M, float qx,
+                                             float qy, float qz, float tau) {
+  if (2 * node + 1 < M) {
+    const f16v ba = box2[2 * node], bb = box2[2 * node + 1];
+    const f2v q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
+    const f2v m01 = box_dist_pk(q2x, q2y, q2z, f2v{ba[0], ba[8]}, f2v{ba[1], ba[9]}, f2v{ba[2], ba[10]},
+                                f2v{ba[3], ba[11]}, f2v{ba[4], ba[12]}, f2v{ba[5], ba[13]});
+    const f2v m23 = box_dist_pk(q2x, q2y, q2z, f2v{bb[0], bb[8]}, f2v{bb[1], bb[9]}, f2v{bb[2], bb[10]},
+                                f2v{bb[3], bb[11]}, f2v{bb[4], bb[12]}, f2v{bb[5], bb[13]});
+    const float m0 = m01.x, m1 = m01.y, m2 = m23.x, m3 = m23.y;
+    const bool n0 = __any(m0 <= tau), n1 = __any(m1 <= tau), n2 = __any(m2 <= tau), n3 = __any(m3 <= tau);
+    const bool a_first = __popcll(__ballot(fminf(m0, m1) <= fminf(m2, m3))) >= 32;
+    const bool f01 = __popcll(__ballot(m0 <= m1)) >= 32;
+    const bool f23 = __popcll(__ballot(m2 <= m3)) >= 32;
+    const int g = 4 * node;
+#define PCLMI_PUSH_PAIR(base, lowfirst, nlo, nhi) \
+  do {                                            \
+    if (lowfirst) {                               \
+      if (nhi) st.push((base) + 1);               \
+      if (nlo) st.push(base);                     \
+    } else {                                      \
+      if (nlo) st.push(base);                     \
+      if (nhi) st.push((base) + 1);               \
+    }                                             \
+  } while (0)
+    if (a_first) {
+      PCLMI_PUSH_PAIR(g + 2, f23, n2, n3);
+      PCLMI_PUSH_PAIR(g, f01, n0, n1);
+    } else {
+      PCLMI_PUSH_PAIR(g, f01, n0, n1);
+      PCLMI_PUSH_PAIR(g + 2, f23, n2, n3);
+    }
+  } else {
+    const f16v b = box2[node];
+    const f2v q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
+    const f2v m01 = box_dist_pk(q2x, q2y, q2z, f2v{b[0], b[8]}, f2v{b[1], b[9]}, f2v{b[2], b[10]},
+                                f2v{b[3], b[11]}, f2v{b[4], b[12]}, f2v{b[5], b[13]});
+    const float m0 = m01.x, m1 = m01.y;
+    const bool n0 = __any(m0 <= tau), n1 = __any(m1 <= tau);
+    const bool f01 = __popcll(__ballot(m0 <= m1)) >= 32;
+    PCLMI_PUSH_PAIR(2 * node, f01, n0, n1);
+  }
+#undef PCLMI_PUSH_PAIR
+}
+
+
+// Wave-uniform 1-NN search: returns each lane's best 64-bit key (d2 bits << 32 | index) for the
+// lane's query; non-searchable lanes return the initial key (FLT_MAX, 0x7fffffff).
+__device__ __forceinline__ unsigned long long wave_nearest(const TreeView &t, float qx, float qy, float qz,
+                                                           bool searchable, int lane) {
+  unsigned long long best = make_key(3.402823466e+38f, 0x7fffffff);
+  float tau = searchable ? lane_bound<1>(t, qx, qy, qz) : -1.f;
+  LaneStack st{0, 0, lane};
+  st.push(1);
+  const cbox_ptr box = (cbox_ptr)t.box;
+  const cgrp_ptr box2 = (cgrp_ptr)t.box;
+  const cgrp_ptr leaf = (cgrp_ptr)t.leaf;
+  const int M = t.M;
+  while (st.sp > 0) {
+    const int node = st.pop();
+    if (node >= M) {
+      const f8v b = box[node];
+      const cgrp_ptr rec = leaf + (size_t)(node - M) * G;
+      f16v grp[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) grp[g] = rec[g];
+      if (!__any(box_dist(qx, qy, qz, b[0], b[1], b[2], b[3], b[4], b[5]) <= tau)) continue;
+      const f2v q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f2v d2 = sq3_pk(q2x - f2v{grp[g][2 * h], grp[g][2 * h + 1]},
+                                q2y - f2v{grp[g][4 + 2 * h], grp[g][5 + 2 * h]},
+                                q2z - f2v{grp[g][8 + 2 * h], grp[g][9 + 2 * h]});
+          const unsigned long long k0 = make_key(d2.x, __float_as_int(grp[g][12 + 2 * h]));
+          const unsigned long long k1 = make_key(d2.y, __float_as_int(grp[g][13 + 2 * h]));
+          best = k0 < best ? k0 : best;
+          best = k1 < best ? k1 : best;
+        }
+      }
+      tau = fminf(tau, __uint_as_float((unsigned int)(best >> 32)));
+    } else {
+      expand_inner(st, box2, node, M, qx, qy, qz, tau);
+    }
+  }
+  return best;
+}
+
+}  // namespace dev
+}  // namespace pclmi
+#endif
