@@ -54,6 +54,22 @@ int pclmi_device_count(void);
 /* Select the device used by subsequently created trees in this thread (default 0). */
 int pclmi_set_device(int device);
 
+/* Kernel timing -----------------------------------------------------------------------
+ * Stands in for the pcl::ScopeTime / StopWatch instrumentation the reference wraps around its
+ * searches (common/include/pcl/common/time.h:58-133; test/kdtree/test_kdtree.cpp:137,261).
+ * When enabled, the library brackets its dominant kernel of each call (the kNN traversal, the
+ * radius count+fill passes, the fused ICP step) with HIP events recorded on the stream the
+ * kernel is launched on.  pclmi_timing_read waits for the recorded events, adds their
+ * durations to the timer and returns total milliseconds and launch count (reset != 0 zeroes
+ * the timer afterwards).  Off by default; costs two event records per call when on. */
+#define PCLMI_TIMER_KNN 0
+#define PCLMI_TIMER_RADIUS 1
+#define PCLMI_TIMER_ICP_STEP 2
+#define PCLMI_TIMER_ORDER 3 /* query ordering (Morton cell counting sort) */
+#define PCLMI_NTIMERS 4
+int pclmi_timing_enable(int on);
+int pclmi_timing_read(int which, double *total_ms, uint64_t *launches, int reset);
+
 /* Index build ------------------------------------------------------------------------
  * Replaces pcl::KdTreeFLANN::setInputCloud + convertCloudToArray
  * (kdtree/include/pcl/kdtree/impl/kdtree_flann.hpp:46-75,180-249).

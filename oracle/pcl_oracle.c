@@ -633,6 +633,111 @@ void orc_estimate_rigid_svd(const float *src, int ss, const int32_t *sidx, const
   rigid_from_correlation(H, cs, ct, T);
 }
 
+/* The same estimator instantiated with Scalar = double (the template parameter of
+ * TransformationEstimationSVD, transformation_estimation_svd.h:57): centroids, demeaned clouds,
+ * H and the Jacobi SVD all in fp64, result stored as fp32.  Used to pin the HIP path's fp64
+ * moment reduction to 1e-5 where the fp32 instantiation's own accumulation error is larger. */
+static void svd3d(const double A[9], double U[9], double S[3], double V[9]) {
+  double a[9];
+  memcpy(a, A, sizeof(a));
+  double v[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  for (int sweep = 0; sweep < 100; ++sweep) {
+    double off = 0.0;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        double alpha = 0, beta = 0, gamma = 0;
+        for (int r = 0; r < 3; ++r) {
+          alpha += a[r * 3 + p] * a[r * 3 + p];
+          beta += a[r * 3 + q] * a[r * 3 + q];
+          gamma += a[r * 3 + p] * a[r * 3 + q];
+        }
+        if (fabs(gamma) <= 1e-300 || fabs(gamma) <= DBL_EPSILON * 0.25 * sqrt(alpha * beta)) continue;
+        off += fabs(gamma);
+        double zeta = (beta - alpha) / (2.0 * gamma);
+        double tt = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        double c = 1.0 / sqrt(1.0 + tt * tt), sn = c * tt;
+        for (int r = 0; r < 3; ++r) {
+          double x = a[r * 3 + p], y = a[r * 3 + q];
+          a[r * 3 + p] = c * x - sn * y;
+          a[r * 3 + q] = sn * x + c * y;
+          x = v[r * 3 + p];
+          y = v[r * 3 + q];
+          v[r * 3 + p] = c * x - sn * y;
+          v[r * 3 + q] = sn * x + c * y;
+        }
+      }
+    if (off == 0.0) break;
+  }
+  double sv[3];
+  for (int c = 0; c < 3; ++c) sv[c] = sqrt(a[c] * a[c] + a[3 + c] * a[3 + c] + a[6 + c] * a[6 + c]);
+  int ord[3] = {0, 1, 2};
+  for (int i = 0; i < 2; ++i)
+    for (int j = i + 1; j < 3; ++j)
+      if (sv[ord[j]] > sv[ord[i]]) {
+        int t = ord[i];
+        ord[i] = ord[j];
+        ord[j] = t;
+      }
+  for (int c = 0; c < 3; ++c) {
+    S[c] = sv[ord[c]];
+    for (int r = 0; r < 3; ++r) {
+      V[r * 3 + c] = v[r * 3 + ord[c]];
+      U[r * 3 + c] = S[c] > 0.0 ? a[r * 3 + ord[c]] / S[c] : 0.0;
+    }
+  }
+  if (S[2] <= S[0] * 1e-13) { /* rank 2 (planar / 3-point input): complete U, as ComputeFullU does */
+    double u0[3] = {U[0], U[3], U[6]}, u1[3] = {U[1], U[4], U[7]};
+    U[2] = u0[1] * u1[2] - u0[2] * u1[1];
+    U[5] = u0[2] * u1[0] - u0[0] * u1[2];
+    U[8] = u0[0] * u1[1] - u0[1] * u1[0];
+  }
+}
+
+void orc_estimate_rigid_svd_f64(const float *src, int ss, const int32_t *sidx, const float *tgt,
+                                int ts, const int32_t *tidx, int64_t n, float T[16]) {
+  double cs[3] = {0, 0, 0}, ct[3] = {0, 0, 0};
+  for (int64_t i = 0; i < n; ++i) {
+    const float *s = src + (int64_t)(sidx ? sidx[i] : i) * ss;
+    const float *t = tgt + (int64_t)(tidx ? tidx[i] : i) * ts;
+    for (int d = 0; d < 3; ++d) {
+      cs[d] += (double)s[d];
+      ct[d] += (double)t[d];
+    }
+  }
+  for (int d = 0; d < 3; ++d) {
+    cs[d] /= (double)n;
+    ct[d] /= (double)n;
+  }
+  double H[9] = {0};
+  for (int64_t i = 0; i < n; ++i) {
+    const float *s = src + (int64_t)(sidx ? sidx[i] : i) * ss;
+    const float *t = tgt + (int64_t)(tidx ? tidx[i] : i) * ts;
+    double sd[3] = {s[0] - cs[0], s[1] - cs[1], s[2] - cs[2]};
+    double td[3] = {t[0] - ct[0], t[1] - ct[1], t[2] - ct[2]};
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) H[r * 3 + c] += sd[r] * td[c];
+  }
+  double U[9], S[3], V[9];
+  svd3d(H, U, S, V);
+  double dU = U[0] * (U[4] * U[8] - U[5] * U[7]) - U[1] * (U[3] * U[8] - U[5] * U[6]) +
+              U[2] * (U[3] * U[7] - U[4] * U[6]);
+  double dV = V[0] * (V[4] * V[8] - V[5] * V[7]) - V[1] * (V[3] * V[8] - V[5] * V[6]) +
+              V[2] * (V[3] * V[7] - V[4] * V[6]);
+  if (dU * dV < 0)
+    for (int r = 0; r < 3; ++r) V[r * 3 + 2] = -V[r * 3 + 2];
+  mat4_identity(T);
+  for (int r = 0; r < 3; ++r) {
+    double R[3];
+    for (int c = 0; c < 3; ++c) {
+      double sum = 0.0;
+      for (int k = 0; k < 3; ++k) sum += V[r * 3 + k] * U[c * 3 + k];
+      R[c] = sum;
+      T[r * 4 + c] = (float)sum;
+    }
+    T[r * 4 + 3] = (float)(ct[r] - ((R[0] * cs[0] + R[1] * cs[1]) + R[2] * cs[2]));
+  }
+}
+
 /* ------------------------------------------------------------------------------------ */
 int64_t orc_correspondences(const float *src, int64_t ns, int ss, const float *tgt, int64_t nt,
                             int ts, double max_dist, int reciprocal, orc_corr *out) {
@@ -912,6 +1017,7 @@ void orc_icp_default_params(orc_icp_params *p) {
   p->max_correspondence_distance = sqrt(DBL_MAX);
   p->ransac_outlier_threshold = 0.05;
   p->min_correspondences = 3;
+  p->svd_scalar_double = 0;
 }
 
 int orc_icp_align(const orc_icp_params *p, const float *src, int64_t ns, int ss, const float *tgt,
@@ -991,7 +1097,10 @@ int orc_icp_align(const orc_icp_params *p, const float *src, int64_t ns, int ss,
       }
     }
     if (ngood < p->min_correspondences) { rc = -2; break; } /* icp.hpp:153-159 */
-    orc_estimate_rigid_svd(out, 4, sgood, target, 4, tgood, ngood, T); /* icp.hpp:171 */
+    if (p->svd_scalar_double) /* icp.hpp:171 */
+      orc_estimate_rigid_svd_f64(out, 4, sgood, target, 4, tgood, ngood, T);
+    else
+      orc_estimate_rigid_svd(out, 4, sgood, target, 4, tgood, ngood, T);
     orc_transform(out, ns, 4, T);                                     /* icp.hpp:174 */
     mat4_mul(T, final_T, final_T);                                    /* icp.hpp:177 */
     ++iters;

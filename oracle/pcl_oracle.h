@@ -80,6 +80,11 @@ void orc_transform(float *pts, int64_t n, int stride, const float T[16]);
 void orc_estimate_rigid_svd(const float *src, int sstride, const int32_t *sidx,
                             const float *tgt, int tstride, const int32_t *tidx, int64_t n,
                             float T[16]);
+/* Same estimator with the reference's Scalar template parameter = double
+ * (transformation_estimation_svd.h:57): every accumulation and the SVD in fp64. */
+void orc_estimate_rigid_svd_f64(const float *src, int sstride, const int32_t *sidx,
+                                const float *tgt, int tstride, const int32_t *tidx, int64_t n,
+                                float T[16]);
 
 /* CorrespondenceEstimation::determine[Reciprocal]Correspondences
  * (registration/include/pcl/registration/impl/correspondence_estimation.hpp:83-141,144-233);
@@ -114,6 +119,7 @@ typedef struct {
   double max_correspondence_distance; /* default sqrt(DBL_MAX) */
   double ransac_outlier_threshold;    /* inlier_threshold_, default 0.05 */
   int min_correspondences;       /* default 3 */
+  int svd_scalar_double;         /* 0: TransformationEstimationSVD<.., float> (default); 1: <.., double> */
 } orc_icp_params;
 
 typedef struct {

@@ -30,6 +30,7 @@ class IcpParams(C.Structure):
         ("max_correspondence_distance", C.c_double),
         ("ransac_outlier_threshold", C.c_double),
         ("min_correspondences", C.c_int),
+        ("svd_scalar_double", C.c_int),
     ]
 
 
@@ -73,6 +74,7 @@ def lib():
                                       c_i64p, C.POINTER(c_i32p), C.POINTER(c_f32p), C.c_int]
         L.orc_transform.argtypes = [c_f32p, c_i64, C.c_int, c_f32p]
         L.orc_estimate_rigid_svd.argtypes = [c_f32p, C.c_int, c_i32p, c_f32p, C.c_int, c_i32p, c_i64, c_f32p]
+        L.orc_estimate_rigid_svd_f64.argtypes = L.orc_estimate_rigid_svd.argtypes
         L.orc_correspondences.restype = c_i64
         L.orc_correspondences.argtypes = [c_f32p, c_i64, C.c_int, c_f32p, c_i64, C.c_int, C.c_double, C.c_int,
                                           C.c_void_p]
@@ -182,13 +184,14 @@ def transform(pts, T):
     return out
 
 
-def estimate_rigid_svd(src, tgt, sidx=None, tidx=None):
+def estimate_rigid_svd(src, tgt, sidx=None, tidx=None, scalar_double=False):
     src, tgt = _f32(src), _f32(tgt)
     n = len(sidx) if sidx is not None else len(src)
     si = np.ascontiguousarray(sidx, np.int32) if sidx is not None else None
     ti = np.ascontiguousarray(tidx, np.int32) if tidx is not None else None
     T = np.zeros(16, np.float32)
-    lib().orc_estimate_rigid_svd(_p(src, c_f32p), src.shape[1], _p(si, c_i32p) if si is not None else None,
+    fn = lib().orc_estimate_rigid_svd_f64 if scalar_double else lib().orc_estimate_rigid_svd
+    fn(_p(src, c_f32p), src.shape[1], _p(si, c_i32p) if si is not None else None,
                                  _p(tgt, c_f32p), tgt.shape[1], _p(ti, c_i32p) if ti is not None else None,
                                  n, _p(T, c_f32p))
     return T.reshape(4, 4)

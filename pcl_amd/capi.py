@@ -57,6 +57,8 @@ SIGNATURES = {
     "pclmi_last_error": (C.c_char_p, []),
     "pclmi_device_count": (C.c_int, []),
     "pclmi_set_device": (C.c_int, [C.c_int]),
+    "pclmi_timing_enable": (C.c_int, [C.c_int]),
+    "pclmi_timing_read": (C.c_int, [C.c_int, c_f64p, c_u64p, C.c_int]),
     "pclmi_tree_create": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int,
                                     C.POINTER(C.c_void_p)]),
     "pclmi_tree_destroy": (None, [C.c_void_p]),
@@ -124,6 +126,20 @@ def _pts(a):
 
 def device_count():
     return load_library().pclmi_device_count()
+
+
+TIMER_KNN, TIMER_RADIUS, TIMER_ICP_STEP, TIMER_ORDER = 0, 1, 2, 3
+
+
+def timing_enable(on=True):
+    _check(load_library().pclmi_timing_enable(int(on)))
+
+
+def timing_read(which, reset=True):
+    """Returns (total_ms, launches) of the HIP-event timer `which`."""
+    ms, n = C.c_double(0), C.c_uint64(0)
+    _check(load_library().pclmi_timing_read(which, C.byref(ms), C.byref(n), int(reset)))
+    return ms.value, n.value
 
 
 class Tree:

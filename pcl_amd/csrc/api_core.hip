@@ -3,6 +3,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <atomic>
 #include <new>
 
 #include <hipcub/hipcub.hpp>
@@ -27,6 +28,40 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line) {
     return PCLMI_ERR_NO_DEVICE;
   if (e == hipErrorOutOfMemory) return PCLMI_ERR_OOM;
   return PCLMI_ERR_HIP;
+}
+
+// ---- kernel timing ---------------------------------------------------------------------------
+namespace {
+struct TimingRec {
+  int which;
+  hipEvent_t a, b;
+};
+std::mutex g_tmu;
+std::vector<TimingRec *> g_pending;
+double g_tms[PCLMI_NTIMERS] = {0};
+uint64_t g_tcalls[PCLMI_NTIMERS] = {0};
+std::atomic<int> g_timing{0};
+}  // namespace
+
+TimingScope::TimingScope(int which, hipStream_t stream) : s(stream) {
+  if (!g_timing.load(std::memory_order_relaxed)) return;
+  TimingRec *r = new TimingRec{which, nullptr, nullptr};
+  if (hipEventCreate(&r->a) != hipSuccess || hipEventCreate(&r->b) != hipSuccess ||
+      hipEventRecord(r->a, s) != hipSuccess) {
+    if (r->a) (void)hipEventDestroy(r->a);
+    if (r->b) (void)hipEventDestroy(r->b);
+    delete r;
+    return;
+  }
+  rec = r;
+}
+
+TimingScope::~TimingScope() {
+  if (!rec) return;
+  TimingRec *r = (TimingRec *)rec;
+  (void)hipEventRecord(r->b, s);
+  std::lock_guard<std::mutex> g(g_tmu);
+  g_pending.push_back(r);
 }
 
 int Workspace::ensure_queries(size_t nq, size_t nbins) {
@@ -113,6 +148,34 @@ int pclmi_set_device(int device) {
   PCLMI_CHECK(device >= 0 && device < n, PCLMI_ERR_INVALID, "device %d out of range (0..%d)", device, n - 1);
   PCLMI_HIP(hipSetDevice(device));
   g_device = device;
+  return PCLMI_OK;
+}
+
+int pclmi_timing_enable(int on) {
+  g_timing.store(on ? 1 : 0);
+  return PCLMI_OK;
+}
+
+int pclmi_timing_read(int which, double *total_ms, uint64_t *launches, int reset) {
+  PCLMI_CHECK(which >= 0 && which < PCLMI_NTIMERS, PCLMI_ERR_INVALID, "unknown timer %d", which);
+  std::lock_guard<std::mutex> g(g_tmu);
+  for (TimingRec *r : g_pending) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r->b) == hipSuccess && hipEventElapsedTime(&ms, r->a, r->b) == hipSuccess) {
+      g_tms[r->which] += ms;
+      g_tcalls[r->which] += 1;
+    }
+    (void)hipEventDestroy(r->a);
+    (void)hipEventDestroy(r->b);
+    delete r;
+  }
+  g_pending.clear();
+  if (total_ms) *total_ms = g_tms[which];
+  if (launches) *launches = g_tcalls[which];
+  if (reset) {
+    g_tms[which] = 0.0;
+    g_tcalls[which] = 0;
+  }
   return PCLMI_OK;
 }
 

@@ -86,6 +86,7 @@ struct pclmi_icp_ctx {
   bool pending = false;   // a transform waits to be applied by the next step / by end()
   float T[16];
   hipStream_t stream = nullptr;
+  hipStream_t user_stream = nullptr;  // stream of the last pclmi_icp_step_dev, when not ours
   double last_thr2 = 0.0;
 };
 
@@ -306,6 +307,7 @@ int pclmi_icp_step_dev(pclmi_icp_ctx *c, double max_correspondence_distance, dou
   PCLMI_CHECK(c && d_sums, PCLMI_ERR_INVALID, "NULL argument");
   PCLMI_HIP(hipSetDevice(c->tree->device));
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  c->user_stream = stream ? s : nullptr;
   const double thr2 = max_correspondence_distance * max_correspondence_distance;  // icp.hpp:57
   c->last_thr2 = thr2;
   launch_icp_step(c->tree, c->pts.p, c->n, c->pending, make_xf(c->T), thr2, c->nn.p, c->dist.p, c->origin,
@@ -327,7 +329,9 @@ int pclmi_icp_set_transform(pclmi_icp_ctx *c, const float T[16]) {
   PCLMI_CHECK(c && T, PCLMI_ERR_INVALID, "NULL argument");
   if (c->pending) {  // two transforms without a step in between: apply the first one now
     PCLMI_HIP(hipSetDevice(c->tree->device));
+    if (c->user_stream) PCLMI_HIP(hipStreamSynchronize(c->user_stream));
     launch_transform(c->pts.p, c->n, make_xf(c->T), c->stream);
+    PCLMI_HIP(hipStreamSynchronize(c->stream));
   }
   std::memcpy(c->T, T, 16 * sizeof(float));
   c->pending = true;
@@ -338,6 +342,7 @@ int pclmi_icp_end(pclmi_icp_ctx *c, float *aligned) {
   if (!c) return PCLMI_OK;
   int rc = PCLMI_OK;
   (void)hipSetDevice(c->tree->device);
+  if (c->user_stream) (void)hipStreamSynchronize(c->user_stream);  // steps enqueued on the caller's stream
   if (aligned && c->n) {
     if (c->pending) launch_transform(c->pts.p, c->n, make_xf(c->T), c->stream);
     DevBuf<float4> outb;

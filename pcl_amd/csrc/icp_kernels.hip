@@ -352,9 +352,12 @@ void launch_icp_step(const pclmi_tree *t, float4 *d_pts, size_t n, bool apply, c
                      int *d_nn, float *d_dist, const double origin[3], double *d_partials, double *d_sums,
                      hipStream_t s) {
   const unsigned blocks = icp_step_blocks(n);
-  hipLaunchKernelGGL(icp_step_kernel, dim3(blocks), dim3(64 * ICP_WPB), 0, s, t->view(), d_pts, (int)n,
-                     apply ? 1 : 0, T, (float)thr2, thr2, (const float4 *)t->d_cloud, d_nn, d_dist, origin[0],
-                     origin[1], origin[2], d_partials);
+  {
+    TimingScope ts(PCLMI_TIMER_ICP_STEP, s);
+    hipLaunchKernelGGL(icp_step_kernel, dim3(blocks), dim3(64 * ICP_WPB), 0, s, t->view(), d_pts, (int)n,
+                       apply ? 1 : 0, T, (float)thr2, thr2, (const float4 *)t->d_cloud, d_nn, d_dist, origin[0],
+                       origin[1], origin[2], d_partials);
+  }
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(NS), dim3(256), 0, s, d_partials, (int)blocks, NS, d_sums);
 }
 

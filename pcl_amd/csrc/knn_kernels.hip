@@ -415,6 +415,7 @@ int launch_morton_order(const pclmi_tree *t, Workspace *w, const float *d_q, siz
     float ext = bb_hi[d] - bb_lo[d];
     sc[d] = ext > 0.f ? 1024.f / ext : 0.f;
   }
+  TimingScope ts(PCLMI_TIMER_ORDER, s);
   PCLMI_HIP(hipMemsetAsync(w->hist, 0, nbins * sizeof(unsigned int), s));
   const unsigned grid = (unsigned)((nq + 255) / 256);
   hipLaunchKernelGGL(cell_count_kernel, dim3(grid), dim3(256), 0, s, d_q, (int)q_stride_f, (int)nq,
@@ -442,6 +443,7 @@ int launch_knn(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, s
                const int32_t *order, int k_eff, int32_t *d_idx, float *d_d2, hipStream_t s) {
   if (nq == 0 || k_eff <= 0) return PCLMI_OK;
   PCLMI_CHECK(nq < (size_t)1 << 31, PCLMI_ERR_UNSUPPORTED, "more than 2^31-1 queries in one call");
+  TimingScope ts(PCLMI_TIMER_KNN, s);
   if (k_eff == 1) {
     constexpr int WPB = 4;
     unsigned waves = (unsigned)((nq + 63) / 64);

@@ -32,6 +32,14 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
     }                                                                                    \
   } while (0)
 
+// ---- kernel timing (pclmi_timing_*): HIP events around the dominant kernels, on their stream ----
+struct TimingScope {
+  void *rec = nullptr;
+  hipStream_t s = nullptr;
+  TimingScope(int which, hipStream_t stream);  // no-op unless pclmi_timing_enable(1)
+  ~TimingScope();
+};
+
 // ---- device tree ------------------------------------------------------------------------
 // Left-balanced bucket kd-tree in implicit (heap) order: node ids 1 .. 2M-1, children of i
 // are 2i and 2i+1, ids >= M are leaves (leaf number = id - M).  See DESIGN.md "Data layout".

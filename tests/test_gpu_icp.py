@@ -1,0 +1,237 @@
+"""GPU parity of the registration path (through the C ABI) vs the golden vectors and the CPU oracle.
+
+Bars: indices and fp32 distances / transformed points bit-exact; 4x4 transforms within 1e-5 of the
+oracle (north_star) and within the reference tests' own tolerances of the golden matrices.
+"""
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+T_TOL = 1e-5  # north_star: final ICP transforms within 1e-5
+
+
+def f32_sum_tol(n, scale):
+    """Error the reference's fp32 instantiation itself carries: its centroids are running fp32 sums
+    of n coordinates of magnitude `scale` (centroid.hpp:48-75), a random walk of ~sqrt(n) roundings of
+    half an ulp of the running sum (n * scale), divided by n."""
+    return 4 * np.sqrt(n) * np.finfo(np.float32).eps * scale
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from pcl_amd import capi as c
+    assert c.device_count() > 0, "no HIP device: the GPU tests must run on the MI355X box"
+    return c
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import pcl_oracle
+    return pcl_oracle
+
+
+def rigid(angle_deg, axis, trans):
+    a = np.asarray(axis, np.float64)
+    a /= np.linalg.norm(a)
+    th = np.deg2rad(angle_deg)
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    R = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = trans
+    return T.astype(np.float32)
+
+
+def surface_cloud(n, seed):
+    """Points on a wavy sheet + a few planes: a 2-manifold-like cloud (SURVEY 8d surface variant)."""
+    rng = np.random.default_rng(seed)
+    uv = rng.random((n, 2), dtype=np.float32) * 100
+    z = 5 * np.sin(uv[:, 0] * 0.1) * np.cos(uv[:, 1] * 0.07) + rng.integers(0, 3, n) * 20
+    return np.stack([uv[:, 0], uv[:, 1], z.astype(np.float32)], axis=1).astype(np.float32)
+
+
+def test_transform_bit_exact(capi, orc):
+    pts = util.uniform_cloud(5000, 3, -50, 50)
+    T = rigid(33, (1, 2, 3), (4, -5, 6))
+    g = capi.transform(pts, T)
+    o = orc.transform(pts, T)
+    assert np.array_equal(g.view(np.int32), o.view(np.int32))
+    # non-finite rows are left untouched (transforms.hpp:196-204)
+    pts[7] = np.nan
+    pts[11, 2] = np.inf
+    g = capi.transform(pts, T)
+    assert np.isnan(g[7]).all() and np.array_equal(g[11], pts[11])
+    # 16-byte PointXYZ rows keep their 4th float
+    p4 = np.concatenate([pts[:100], np.full((100, 1), 1, np.float32)], axis=1)
+    g4 = capi.transform(p4, T)
+    assert np.array_equal(g4[:, 3], p4[:, 3]) and np.array_equal(g4[:20, :3], g[:20], equal_nan=True)
+
+
+def test_bun_correspondences_golden(capi, orc):
+    api = util.golden("registration_api.json")
+    src, tgt = util.bun0(), util.bun4()
+    tt, ts = capi.Tree(tgt), capi.Tree(src)
+    corr = capi.correspondences(tt, src)
+    exp = np.array(api["correspondences_original"])
+    assert corr["index_query"].tolist() == exp[:, 0].tolist()
+    assert corr["index_match"].tolist() == exp[:, 1].tolist()
+    oc = orc.correspondences(src, tgt)
+    assert np.array_equal(corr["distance"].view(np.int32), oc["distance"].view(np.int32))
+    rec = capi.correspondences_reciprocal(tt, ts, src, tgt)
+    exp = np.array(api["correspondences_reciprocal"])
+    assert rec["index_query"].tolist() == exp[:, 0].tolist()
+    assert rec["index_match"].tolist() == exp[:, 1].tolist()
+    # max distance is a non-strict keep (correspondence_estimation.hpp:108)
+    md = 0.01
+    c2 = capi.correspondences(tt, src, md)
+    o2 = orc.correspondences(src, tgt, md)
+    assert np.array_equal(c2, o2)
+    # an index view of the source (PCLBase indices_)
+    view = np.arange(0, 397, 3, dtype=np.int32)
+    c3 = capi.correspondences(tt, src, src_indices=view)
+    assert c3["index_query"].tolist() == view.tolist()
+    assert c3["index_match"].tolist() == exp_match(api, view)
+
+
+def exp_match(api, view):
+    exp = np.array(api["correspondences_original"])
+    return exp[view, 1].tolist()
+
+
+def test_bun_transformation_estimation_svd(capi, orc):
+    api = util.golden("registration_api.json")
+    src, tgt = util.bun0(), util.bun4()
+    rec = orc.correspondences(src, tgt, reciprocal=True)
+    T = capi.estimate_rigid_svd(src, tgt, rec["index_query"], rec["index_match"])
+    assert np.allclose(T, np.array(api["transform_from_SVD"]), atol=1e-4)  # the reference test's bar
+    To = orc.estimate_rigid_svd(src, tgt, rec["index_query"], rec["index_match"])
+    assert np.abs(T - To).max() <= T_TOL
+    assert T[3].tolist() == [0, 0, 0, 1]
+    # recover a known rigid motion from exact pairs
+    pts = util.uniform_cloud(20000, 5, -10, 10)
+    Tk = rigid(17, (0.3, -1, 2), (1, 2, -3))
+    moved = orc.transform(pts, Tk)
+    Te = capi.estimate_rigid_svd(pts, moved)
+    assert np.abs(Te - Tk).max() < 2e-5
+
+
+@pytest.mark.parametrize("ransac", [0, 1000])
+def test_bun_full_icp_golden(capi, orc, ransac):
+    # test/registration/test_registration.cpp:154-188
+    g = util.golden("icp_bun0_bun4.json")
+    src, tgt = util.bun0(), util.bun4()
+    tt = capi.Tree(tgt)
+    p = capi.icp_default_params()
+    p.max_iterations = g["max_iterations"]
+    p.transformation_epsilon = g["transformation_epsilon"]
+    p.max_correspondence_distance = g["max_correspondence_distance"]
+    p.ransac_iterations = ransac
+    rc, T, out, st = capi.icp_align(tt, src, p)
+    assert rc == 0 and st.converged
+    gold, tol = np.array(g["matrix"]), np.array(g["tol"])
+    assert np.all(np.abs(T[:3] - gold[:3]) <= tol[:3]), (T, gold)
+    assert T[3].tolist() == [0, 0, 0, 1]
+    po = orc.icp_default_params()
+    po.max_iterations, po.transformation_epsilon = p.max_iterations, p.transformation_epsilon
+    po.max_correspondence_distance, po.ransac_iterations = p.max_correspondence_distance, ransac
+    rco, To, outo, sto = orc.icp_align(src, tgt, po)
+    # transformation_epsilon = 1e-8: the fp64 solve reaches the fixed point exactly (T == T_prev) and
+    # stops, the reference's fp32 solve keeps jittering by ~1e-7 until max_iterations - same fixed point
+    assert st.iterations <= sto.iterations
+    assert st.last_correspondences == sto.last_correspondences
+    assert np.abs(T - To).max() <= T_TOL, np.abs(T - To).max()
+    assert np.allclose(out[:, :3], outo[:, :3], atol=2e-5)
+    assert np.array_equal(out[:, 3], np.ones(397, np.float32))
+    # getFitnessScore (registration.hpp:71-109)
+    fg = capi.fitness_score(tt, src, T)
+    fo = orc.fitness_score(src, tgt, T)
+    assert abs(fg - fo) <= 1e-12 + 1e-9 * abs(fo)
+
+
+@pytest.mark.parametrize("n,ransac", [(30000, 0), (30000, 1000), (200_000, 0)])
+def test_synthetic_icp_vs_oracle(capi, orc, n, ransac):
+    tgt = surface_cloud(n, 41)
+    rng = np.random.default_rng(42)
+    sel = rng.permutation(n)[: (n * 9) // 10]
+    T0 = rigid(2.0, (1, 1, 1), (0.4, -0.2, 0.1))
+    src = orc.transform(tgt[sel] + rng.normal(0, 0.01, (len(sel), 3)).astype(np.float32), np.linalg.inv(T0))
+    tt = capi.Tree(tgt)
+    p = capi.icp_default_params()
+    p.max_iterations = 12
+    p.max_correspondence_distance = 3.0
+    p.ransac_iterations = ransac
+    p.ransac_outlier_threshold = 0.5
+    rc, T, out, st = capi.icp_align(tt, src, p)
+    po = orc.icp_default_params()
+    po.max_iterations, po.max_correspondence_distance = 12, 3.0
+    po.ransac_iterations, po.ransac_outlier_threshold = ransac, 0.5
+    # the 1e-5 bar is against the reference estimator instantiated with Scalar = double
+    # (transformation_estimation_svd.h:57); its fp32 instantiation is itself only accurate to
+    # f32_sum_tol at this size (on the reference's own bun fixture both agree to 1e-5, see above)
+    po.svd_scalar_double = 1
+    rco, To, outo, sto = orc.icp_align(src, tgt, po, nthreads=8)
+    assert rc == 0 and rco == 0
+    assert st.iterations == sto.iterations == 12
+    assert st.last_correspondences == sto.last_correspondences
+    assert np.abs(T - To).max() <= T_TOL, np.abs(T - To).max()
+    po.svd_scalar_double = 0
+    rco, To32, outo, sto = orc.icp_align(src, tgt, po, nthreads=8)
+    assert np.abs(T - To32).max() <= f32_sum_tol(len(src), 100.0), np.abs(T - To32).max()
+    if n <= 30000:
+        assert np.abs(T - T0).max() < 5e-3  # and it actually registers the clouds
+
+
+def test_icp_guess_threshold_and_not_enough(capi, orc):
+    tgt = surface_cloud(20000, 51)
+    T0 = rigid(3.0, (0, 0, 1), (0.5, 0.5, 0))
+    src = orc.transform(tgt[::2], np.linalg.inv(T0))
+    tt = capi.Tree(tgt)
+    p = capi.icp_default_params()
+    p.ransac_iterations = 0
+    p.max_iterations = 5
+    p.max_correspondence_distance = 2.0
+    guess = rigid(2.5, (0, 0, 1), (0.4, 0.4, 0))
+    rc, T, out, st = capi.icp_align(tt, src, p, guess=guess)
+    po = orc.icp_default_params()
+    po.ransac_iterations, po.max_iterations, po.max_correspondence_distance = 0, 5, 2.0
+    po.svd_scalar_double = 1
+    rco, To, outo, sto = orc.icp_align(src, tgt, po, guess=guess, nthreads=8)
+    assert rc == 0 and np.abs(T - To).max() <= T_TOL
+    # transformation_epsilon stops early (icp.hpp:194)
+    p.max_iterations, po.max_iterations = 100, 100
+    p.transformation_epsilon = po.transformation_epsilon = 1e-4
+    rc, T, out, st = capi.icp_align(tt, src, p, guess=guess)
+    rco, To, outo, sto = orc.icp_align(src, tgt, po, guess=guess, nthreads=8)
+    assert st.iterations == sto.iterations < 100 and st.converged
+    # far-away source: fewer than 3 pairs under the threshold (icp.hpp:103-108)
+    far = src + np.float32(1e4)
+    p.max_correspondence_distance = 1.0
+    rc, T, out, st = capi.icp_align(tt, far, p)
+    assert rc == 6 and not st.converged
+
+
+def test_sharded_steps_equal_single_shard(capi, orc):
+    """Two shards + summed fp64 moments + the shared host solve == one shard."""
+    tgt = surface_cloud(50000, 61)
+    T0 = rigid(1.5, (1, 0, 1), (0.3, 0.1, -0.2))
+    src = orc.transform(tgt[::3], np.linalg.inv(T0))
+    tt = capi.Tree(tgt)
+    one = capi.IcpShard(tt, src)
+    half = len(src) // 2
+    a, b = capi.IcpShard(tt, src[:half]), capi.IcpShard(tt, src[half:])
+    for it in range(4):
+        s1 = one.step(2.0)
+        s2 = a.step(2.0) + b.step(2.0)
+        assert s1[0] == s2[0] and s1[18] == s2[18]  # pair and point counts are exact
+        assert np.allclose(s1[:19], s2[:19], rtol=1e-12, atol=1e-9)
+        T1, T2 = capi.icp_solve(s1), capi.icp_solve(s2)
+        assert np.abs(T1 - T2).max() <= 1e-6
+        one.set_transform(T1)
+        a.set_transform(T1)
+        b.set_transform(T1)
+    o1 = one.end()
+    oa, ob = a.end(), b.end()
+    assert np.array_equal(o1, np.concatenate([oa, ob]))

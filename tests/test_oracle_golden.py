@@ -86,6 +86,10 @@ def test_bun_transformation_estimation_svd():
     rec = orc.correspondences(src, tgt, reciprocal=True)
     T = orc.estimate_rigid_svd(src, tgt, rec["index_query"], rec["index_match"])
     assert np.allclose(T, np.array(api["transform_from_SVD"]), atol=1e-4)
+    # the Scalar = double instantiation (transformation_estimation_svd.h:57) meets the same golden
+    Td = orc.estimate_rigid_svd(src, tgt, rec["index_query"], rec["index_match"], scalar_double=True)
+    assert np.allclose(Td, np.array(api["transform_from_SVD"]), atol=1e-4)
+    assert np.abs(Td - T).max() < 1e-5
 
 
 @pytest.mark.parametrize("ransac", [1000, 0])
@@ -106,6 +110,11 @@ def test_bun_full_icp(ransac):
     assert out.shape == (397, 4)
     # registered cloud == final transform applied to the source (within fp32 chain rounding)
     assert np.allclose(out[:, :3], orc.transform(src, T), atol=1e-5)
+    # ... and so does the loop run with the Scalar = double estimator
+    p.svd_scalar_double = 1
+    rc, Td, out, st = orc.icp_align(src, tgt, p)
+    assert rc == 0 and np.all(np.abs(Td[:3] - gold[:3]) <= tol[:3])
+    assert np.abs(Td - T).max() < 1e-5
 
 
 def test_tree_matches_brute_force_with_ties():
