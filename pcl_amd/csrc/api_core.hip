@@ -103,7 +103,20 @@ int Workspace::ensure_scratch(size_t bytes) {
   return PCLMI_OK;
 }
 
+int Workspace::ensure_buf(int which, size_t bytes) {
+  if (bytes <= cap_buf[which]) return PCLMI_OK;
+  if (buf[which]) (void)hipFree(buf[which]);
+  buf[which] = nullptr;
+  cap_buf[which] = 0;
+  size_t cap = bytes + bytes / 8 + 4096;
+  PCLMI_HIP(hipMalloc(&buf[which], cap));
+  cap_buf[which] = cap;
+  return PCLMI_OK;
+}
+
 void Workspace::release() {
+  for (int i = 0; i < 4; ++i)
+    if (buf[i]) (void)hipFree(buf[i]);
   if (keys_in) (void)hipFree(keys_in);
   if (vals_out) (void)hipFree(vals_out);
   if (hist) (void)hipFree(hist);

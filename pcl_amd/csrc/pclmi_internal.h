@@ -87,8 +87,12 @@ struct Workspace {
   // generic scratch (large-k heaps, radius counts, ...)
   void *scratch = nullptr;
   size_t cap_scratch = 0;
+  // further independent scratch buffers (radius search: counts/offsets, key arrays, sort temp)
+  void *buf[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t cap_buf[4] = {0, 0, 0, 0};
   int ensure_queries(size_t nq, size_t nbins);
   int ensure_scratch(size_t bytes);
+  int ensure_buf(int which, size_t bytes);
   void release();
 };
 
@@ -120,6 +124,12 @@ int launch_morton_order(const pclmi_tree *t, Workspace *w, const float *d_q, siz
 int launch_knn(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, size_t q_stride_f,
                const int32_t *d_order, int k_eff, int32_t *d_idx, float *d_d2, hipStream_t s);
 
+
+// ---- radius search (radius_kernels.hip) ---------------------------------------------------
+// Whole device-side pipeline of pclmi_radius_dev; *d_idx / *d_d2 are hipMalloc'd here.
+int radius_search_dev(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, size_t q_stride_f,
+                      float r2, uint32_t max_nn, int sorted, uint64_t *d_offsets, int32_t **d_idx,
+                      float **d_d2, uint64_t *total, hipStream_t s);
 
 // ---- ICP / registration kernels (icp_kernels.hip) -----------------------------------------
 struct Xf {

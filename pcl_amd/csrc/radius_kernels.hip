@@ -1,0 +1,419 @@
+// radius_kernels.hip - fixed-radius neighbour search on gfx950 (MI355X), wave64.
+//
+// Replaces the FLANN traversal behind pcl::KdTreeFLANN::radiusSearch
+// (kdtree/include/pcl/kdtree/impl/kdtree_flann.hpp:115-157): all points with d2 < (float)(r*r)
+// (strict), optionally only the nearest max_nn, ascending by (d2, index) when sorted, by index
+// otherwise.  The output is variable length, so the search runs as
+//   1. count pass   - the wave-uniform union traversal of traverse.hpp, every lane counting the hits
+//                     of its own query;
+//   2. exclusive scan of the counts -> CSR offsets (the only host synchronisation: the total);
+//   3. fill pass    - the same traversal again, every lane appending 64-bit keys
+//                     (d2 bits << 32 | index, or index << 32 | d2 bits for unsorted output) to its
+//                     own segment;
+//   4. per-segment sort of the keys (an in-LDS bitonic network per segment up to 1024 entries,
+//                     hipcub::DeviceSegmentedSort for the rare longer ones);
+//   5. split of the keys into the idx / d2 arrays (and truncation to max_nn).
+// Queries are visited in Morton-cell order like the kNN path; segments are laid out in the caller's
+// query order.
+#include <hipcub/hipcub.hpp>
+
+#include "pclmi_internal.h"
+#include "traverse.hpp"
+
+namespace pclmi {
+namespace {
+
+using namespace dev;
+typedef unsigned long long u64;
+
+constexpr int R_WPB = 4;
+
+template <bool FILL>
+__global__ __launch_bounds__(64 * R_WPB) void radius_union_kernel(TreeView t, const float *__restrict__ q,
+                                                                   int q_stride_f,
+                                                                   const int *__restrict__ order, int nq,
+                                                                   float r2, float tau_r, int by_index,
+                                                                   unsigned int *__restrict__ counts,
+                                                                   const u64 *__restrict__ offsets,
+                                                                   u64 *__restrict__ keys) {
+  const int lane = threadIdx.x & 63;
+  LaneQuery lq;
+  if (!load_lane_query<R_WPB>(q, q_stride_f, order, nq, lq)) return;
+  const float qx = lq.x, qy = lq.y, qz = lq.z;
+  // a box can hold a hit iff its distance is < r2, i.e. <= tau_r = the largest float below r2;
+  // lanes without a searchable query get a negative bound and never steer the wave
+  const float tau = lq.searchable ? tau_r : -1.f;
+  unsigned int cnt = 0;
+  u64 *out = nullptr;
+  if (FILL && lq.alive) out = keys + offsets[lq.qi];
+
+  LaneStack st{0, 0, lane};
+  st.push(1);
+  const cbox_ptr box = (cbox_ptr)t.box;
+  const cgrp_ptr box2 = (cgrp_ptr)t.box;
+  const cgrp_ptr leaf = (cgrp_ptr)t.leaf;
+  const int M = t.M;
+  while (st.sp > 0) {
+    const int node = st.pop();
+    if (node >= M) {
+      const f8v b = box[node];
+      const cgrp_ptr rec = leaf + (size_t)(node - M) * G;
+      f16v grp[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) grp[g] = rec[g];
+      if (!__any(box_dist(qx, qy, qz, b[0], b[1], b[2], b[3], b[4], b[5]) <= tau)) continue;
+      const f2v q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        float dd[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f2v d2 = sq3_pk(q2x - f2v{grp[g][2 * h], grp[g][2 * h + 1]},
+                                q2y - f2v{grp[g][4 + 2 * h], grp[g][5 + 2 * h]},
+                                q2z - f2v{grp[g][8 + 2 * h], grp[g][9 + 2 * h]});
+          dd[2 * h] = d2.x;
+          dd[2 * h + 1] = d2.y;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          // padded slots sit at 3e38: their d2 is +inf and never < r2; NaN queries never pass
+          if (dd[j] < r2) {
+            if (FILL) {
+              const unsigned int ib = __float_as_uint(grp[g][12 + j]), db = __float_as_uint(dd[j]);
+              out[cnt] = by_index ? (((u64)ib << 32) | db) : (((u64)db << 32) | ib);
+            }
+            ++cnt;
+          }
+        }
+      }
+    } else {
+      expand_inner(st, box2, node, M, qx, qy, qz, tau);
+    }
+  }
+  if (!FILL && lq.alive) counts[lq.qi] = cnt;
+}
+
+// ---- per-segment sort ------------------------------------------------------------------------
+// One wave per segment of up to SEG_MAX keys: load into LDS (padded with ~0), bitonic network,
+// store back.  Short segments (the common case, ~32 entries) take log^2 steps over 64 slots.
+// Segments longer than SEG_MAX are left for the hipcub pass (their count is returned in *n_long).
+constexpr int SEG_MAX = 1024;
+
+// one single-wave block per segment, so that __syncthreads() is a wave-local barrier
+__global__ __launch_bounds__(64) void segment_sort_kernel(u64 *__restrict__ keys, const u64 *__restrict__ offsets,
+                                                          int nq, unsigned int *__restrict__ n_long) {
+  __shared__ u64 s[SEG_MAX];
+  const int lane = threadIdx.x;
+  const int seg = blockIdx.x;
+  const u64 a = offsets[seg], b = offsets[seg + 1];
+  const u64 len64 = b - a;
+  if (len64 < 2) return;  // block-uniform
+  if (len64 > (u64)SEG_MAX) {
+    if (lane == 0) atomicAdd(n_long, 1u);
+    return;
+  }
+  const int len = (int)len64;
+  int P = 64;
+  while (P < len) P <<= 1;
+  for (int i = lane; i < P; i += 64) s[i] = i < len ? keys[a + i] : ~0ull;
+  __syncthreads();
+  for (int size = 2; size <= P; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int i = lane; i < P / 2; i += 64) {
+        const int lo = 2 * i - (i & (stride - 1));  // i-th index with bit `stride` clear
+        const int hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        const u64 x = s[lo], y = s[hi];
+        const bool sw = up ? (y < x) : (x < y);
+        if (sw) {
+          s[lo] = y;
+          s[hi] = x;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = lane; i < len; i += 64) keys[a + i] = s[i];
+}
+
+// offsets for hipcub: segments handled by segment_sort_kernel are presented as empty
+__global__ void long_segment_bounds_kernel(const u64 *__restrict__ offsets, int nq, u64 *__restrict__ beg,
+                                           u64 *__restrict__ end) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  const u64 a = offsets[i], b = offsets[i + 1];
+  beg[i] = a;
+  end[i] = (b - a > (u64)SEG_MAX) ? b : a;
+}
+
+__global__ void clamp_counts_kernel(unsigned int *__restrict__ counts, int nq, unsigned int max_nn) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nq) counts[i] = min(counts[i], max_nn);
+}
+
+// keys -> idx / d2 (no truncation): purely elementwise
+__global__ void split_kernel(const u64 *__restrict__ keys, u64 total, int by_index, int *__restrict__ idx,
+                             float *__restrict__ d2) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const u64 k = keys[i];
+  const unsigned int hi = (unsigned int)(k >> 32), lo = (unsigned int)k;
+  idx[i] = (int)(by_index ? hi : lo);
+  d2[i] = __uint_as_float(by_index ? lo : hi);
+}
+
+// truncation to the nearest max_nn: one wave per query copies the head of its (d2, index)-sorted
+// segment.  to_keys != null: emit index-major keys (for the second, by-index sort) instead.
+__global__ __launch_bounds__(256) void truncate_kernel(const u64 *__restrict__ keys,
+                                                       const u64 *__restrict__ off_full,
+                                                       const u64 *__restrict__ off_out, int nq,
+                                                       int *__restrict__ idx, float *__restrict__ d2,
+                                                       u64 *__restrict__ to_keys) {
+  const int lane = threadIdx.x & 63;
+  const int seg = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (seg >= nq) return;
+  const u64 src = off_full[seg], dst = off_out[seg];
+  const int len = (int)(off_out[seg + 1] - dst);
+  for (int i = lane; i < len; i += 64) {
+    const u64 k = keys[src + i];
+    if (to_keys) {
+      to_keys[dst + i] = (k << 32) | (k >> 32);
+    } else {
+      idx[dst + i] = (int)(unsigned int)k;
+      d2[dst + i] = __uint_as_float((unsigned int)(k >> 32));
+    }
+  }
+}
+
+struct CountToU64 {
+  __host__ __device__ u64 operator()(unsigned int c) const { return (u64)c; }
+};
+
+// exclusive scan of counts[0 .. nq] (counts[nq] == 0) into 64-bit offsets[0 .. nq]
+int scan_counts(Workspace *w, const unsigned int *d_counts, size_t nq, u64 *d_offsets, hipStream_t s) {
+  hipcub::TransformInputIterator<u64, CountToU64, const unsigned int *> in(d_counts, CountToU64());
+  size_t need = 0;
+  PCLMI_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, need, in, d_offsets, (int)(nq + 1), s));
+  int rc = w->ensure_buf(3, need + 256);
+  if (rc) return rc;
+  need = w->cap_buf[3];
+  PCLMI_HIP(hipcub::DeviceScan::ExclusiveSum(w->buf[3], need, in, d_offsets, (int)(nq + 1), s));
+  return PCLMI_OK;
+}
+
+// sorts every CSR segment of `keys` ascending; `alt` is a second buffer of the same size (hipcub
+// path only).  On return *sorted_in receives the buffer holding the result.
+int sort_segments(Workspace *w, u64 *keys, u64 *alt, const u64 *d_offsets, size_t nq, u64 total,
+                  unsigned int *d_nlong, u64 **sorted_in, hipStream_t s) {
+  *sorted_in = keys;
+  if (total < 2) return PCLMI_OK;
+  PCLMI_HIP(hipMemsetAsync(d_nlong, 0, sizeof(unsigned int), s));
+  hipLaunchKernelGGL(segment_sort_kernel, dim3((unsigned)nq), dim3(64), 0, s, keys, d_offsets, (int)nq, d_nlong);
+  unsigned int n_long = 0;
+  PCLMI_HIP(hipMemcpyAsync(&n_long, d_nlong, sizeof(n_long), hipMemcpyDeviceToHost, s));
+  PCLMI_HIP(hipStreamSynchronize(s));
+  if (n_long == 0) return PCLMI_OK;
+  // rare: some segments exceed the LDS network; sort those with hipcub, in place via a copy
+  PCLMI_CHECK(total < ((u64)1 << 31), PCLMI_ERR_UNSUPPORTED,
+              "radius search: a segment longer than %d entries in a batch of more than 2^31-1 results", SEG_MAX);
+  int rc = w->ensure_buf(2, nq * 2 * sizeof(u64));
+  if (rc) return rc;
+  u64 *beg = (u64 *)w->buf[2], *end = beg + nq;
+  hipLaunchKernelGGL(long_segment_bounds_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, d_offsets,
+                     (int)nq, beg, end);
+  PCLMI_HIP(hipMemcpyAsync(alt, keys, total * sizeof(u64), hipMemcpyDeviceToDevice, s));
+  size_t need = 0;
+  PCLMI_HIP(hipcub::DeviceSegmentedSort::SortKeys(nullptr, need, (const u64 *)alt, keys, (int)total, (int)nq, beg,
+                                                  end, s));
+  rc = w->ensure_buf(3, need + 256);
+  if (rc) return rc;
+  need = w->cap_buf[3];
+  // hipcub leaves items outside every segment untouched in the output: short segments keep the
+  // already sorted keys that are in `keys`.
+  PCLMI_HIP(hipcub::DeviceSegmentedSort::SortKeys(w->buf[3], need, (const u64 *)alt, keys, (int)total, (int)nq, beg,
+                                                  end, s));
+  return PCLMI_OK;
+}
+
+}  // namespace
+
+int radius_search_dev(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, size_t qsf, float r2,
+                      uint32_t max_nn, int sorted, uint64_t *d_offsets, int32_t **d_idx, float **d_d2,
+                      uint64_t *total_out, hipStream_t s) {
+  *d_idx = nullptr;
+  *d_d2 = nullptr;
+  *total_out = 0;
+  PCLMI_CHECK(nq < ((size_t)1 << 31) - 1, PCLMI_ERR_UNSUPPORTED, "more than 2^31-2 queries in one call");
+  if (max_nn == 0 || (size_t)max_nn > t->n) max_nn = 0;  // impl/kdtree_flann.hpp:125-135
+  if (nq == 0 || t->n == 0 || !(r2 > 0.f)) {  // d2 < r2 is impossible for r2 <= 0 (or NaN)
+    PCLMI_HIP(hipMemsetAsync(d_offsets, 0, (nq + 1) * sizeof(uint64_t), s));
+    PCLMI_HIP(hipStreamSynchronize(s));
+    return PCLMI_OK;
+  }
+  const int32_t *order = nullptr;
+  int rc = launch_morton_order(t, w, d_q, nq, qsf, nullptr, nullptr, s, &order);
+  if (rc) return rc;
+  // buf[0]: counts[nq + 1] (u32) | n_long (u32) | full offsets[nq + 1] (u64, only with max_nn)
+  const size_t counts_bytes = ((nq + 2) * sizeof(unsigned int) + 15) & ~(size_t)15;
+  rc = w->ensure_buf(0, counts_bytes + (nq + 1) * sizeof(u64));
+  if (rc) return rc;
+  unsigned int *d_counts = (unsigned int *)w->buf[0];
+  unsigned int *d_nlong = d_counts + nq + 1;
+  u64 *d_off_full = max_nn ? (u64 *)((char *)w->buf[0] + counts_bytes) : (u64 *)d_offsets;
+  PCLMI_HIP(hipMemsetAsync(d_counts, 0, counts_bytes, s));
+  const float tau_r = nextafterf(r2, 0.f);  // largest float < r2 (r2 > 0)
+  const int by_index = (!sorted && !max_nn) ? 1 : 0;
+  const unsigned waves = (unsigned)((nq + 63) / 64);
+  const unsigned blocks = ((waves + R_WPB - 1) / R_WPB + 7) & ~7u;
+  {
+    TimingScope ts(PCLMI_TIMER_RADIUS, s);
+    hipLaunchKernelGGL((radius_union_kernel<false>), dim3(blocks), dim3(64 * R_WPB), 0, s, t->view(), d_q, (int)qsf,
+                       order, (int)nq, r2, tau_r, by_index, d_counts, (const u64 *)nullptr, (u64 *)nullptr);
+  }
+  rc = scan_counts(w, d_counts, nq, d_off_full, s);
+  if (rc) return rc;
+  u64 total = 0;
+  PCLMI_HIP(hipMemcpyAsync(&total, d_off_full + nq, sizeof(u64), hipMemcpyDeviceToHost, s));
+  PCLMI_HIP(hipStreamSynchronize(s));
+  if (total == 0) {
+    if (max_nn) PCLMI_HIP(hipMemsetAsync(d_offsets, 0, (nq + 1) * sizeof(uint64_t), s));
+    PCLMI_HIP(hipStreamSynchronize(s));
+    return PCLMI_OK;
+  }
+  // buf[1]: keys[total] | alt[total]
+  rc = w->ensure_buf(1, 2 * total * sizeof(u64));
+  if (rc) return rc;
+  u64 *keys = (u64 *)w->buf[1], *alt = keys + total;
+  {
+    TimingScope ts(PCLMI_TIMER_RADIUS, s);
+    hipLaunchKernelGGL((radius_union_kernel<true>), dim3(blocks), dim3(64 * R_WPB), 0, s, t->view(), d_q, (int)qsf,
+                       order, (int)nq, r2, tau_r, by_index, (unsigned int *)nullptr, (const u64 *)d_off_full, keys);
+  }
+  u64 *res = nullptr;
+  rc = sort_segments(w, keys, alt, d_off_full, nq, total, d_nlong, &res, s);
+  if (rc) return rc;
+
+  u64 out_total = total;
+  if (max_nn) {
+    hipLaunchKernelGGL(clamp_counts_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, d_counts, (int)nq,
+                       (unsigned int)max_nn);
+    rc = scan_counts(w, d_counts, nq, (u64 *)d_offsets, s);
+    if (rc) return rc;
+    PCLMI_HIP(hipMemcpyAsync(&out_total, d_offsets + nq, sizeof(u64), hipMemcpyDeviceToHost, s));
+    PCLMI_HIP(hipStreamSynchronize(s));
+  }
+  int32_t *oi = nullptr;
+  float *od = nullptr;
+  hipError_t e;
+  if ((e = hipMalloc(&oi, out_total * sizeof(int32_t))) != hipSuccess ||
+      (e = hipMalloc(&od, out_total * sizeof(float))) != hipSuccess) {
+    if (oi) (void)hipFree(oi);
+    return hip_fail(e, "radius result allocation", __FILE__, __LINE__);
+  }
+  auto fail = [&](int code) {
+    (void)hipFree(oi);
+    (void)hipFree(od);
+    return code;
+  };
+  const unsigned seg_blocks = (unsigned)((nq + 3) / 4);
+  if (!max_nn) {
+    hipLaunchKernelGGL(split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const u64 *)res, total,
+                       by_index, oi, od);
+  } else if (sorted) {
+    hipLaunchKernelGGL(truncate_kernel, dim3(seg_blocks), dim3(256), 0, s, (const u64 *)res,
+                       (const u64 *)d_off_full, (const u64 *)d_offsets, (int)nq, oi, od, (u64 *)nullptr);
+  } else {
+    // nearest max_nn, then ascending index: truncate into index-major keys, sort again, split
+    u64 *other = (res == keys) ? alt : keys;
+    hipLaunchKernelGGL(truncate_kernel, dim3(seg_blocks), dim3(256), 0, s, (const u64 *)res,
+                       (const u64 *)d_off_full, (const u64 *)d_offsets, (int)nq, (int *)nullptr, (float *)nullptr,
+                       other);
+    // max_nn <= SEG_MAX keeps every truncated segment inside the LDS network; beyond that the
+    // hipcub path needs a free second buffer: reuse the source buffer (its content is dead now)
+    u64 *res2 = nullptr;
+    rc = sort_segments(w, other, res, (const u64 *)d_offsets, nq, out_total, d_nlong, &res2, s);
+    if (rc) return fail(rc);
+    hipLaunchKernelGGL(split_kernel, dim3((unsigned)((out_total + 255) / 256)), dim3(256), 0, s, (const u64 *)res2,
+                       out_total, 1, oi, od);
+  }
+  if ((e = hipGetLastError()) != hipSuccess || (e = hipStreamSynchronize(s)) != hipSuccess)
+    return fail(hip_fail(e, "radius search", __FILE__, __LINE__));
+  *d_idx = oi;
+  *d_d2 = od;
+  *total_out = out_total;
+  return PCLMI_OK;
+}
+
+}  // namespace pclmi
+
+using namespace pclmi;
+
+extern "C" {
+
+int pclmi_radius_dev(const pclmi_tree *t, const float *d_q, size_t nq, size_t q_stride_bytes, double radius,
+                     uint32_t max_nn, int sorted, uint64_t *d_offsets, int32_t **d_idx, float **d_d2,
+                     uint64_t *total, void *stream) {
+  PCLMI_CHECK(t && d_offsets && d_idx && d_d2 && total, PCLMI_ERR_INVALID, "NULL argument");
+  PCLMI_CHECK(nq == 0 || d_q, PCLMI_ERR_INVALID, "queries are NULL");
+  PCLMI_CHECK(q_stride_bytes >= 12 && q_stride_bytes % 4 == 0, PCLMI_ERR_INVALID, "bad query stride %zu",
+              q_stride_bytes);
+  PCLMI_CHECK(pclmi_device_count() > 0, PCLMI_ERR_NO_DEVICE, "no HIP device visible: libpclmi has no CPU fallback");
+  PCLMI_HIP(hipSetDevice(t->device));
+  hipStream_t s = stream ? (hipStream_t)stream : t->stream;
+  const float r2 = (float)(radius * radius);  // impl/kdtree_flann.hpp:140
+  WsGuard g(t);
+  return radius_search_dev(t, g.w, d_q, nq, q_stride_bytes / 4, r2, max_nn, sorted, d_offsets, d_idx, d_d2, total,
+                           s);
+}
+
+int pclmi_radius(const pclmi_tree *t, const float *q, size_t nq, size_t q_stride_bytes, double radius,
+                 uint32_t max_nn, int sorted, uint64_t *offsets, int32_t **idx, float **d2) {
+  PCLMI_CHECK(t && offsets && idx && d2, PCLMI_ERR_INVALID, "NULL argument");
+  PCLMI_CHECK(nq == 0 || q, PCLMI_ERR_INVALID, "queries are NULL");
+  PCLMI_CHECK(q_stride_bytes >= 12 && q_stride_bytes % 4 == 0, PCLMI_ERR_INVALID, "bad query stride %zu",
+              q_stride_bytes);
+  PCLMI_CHECK(pclmi_device_count() > 0, PCLMI_ERR_NO_DEVICE, "no HIP device visible: libpclmi has no CPU fallback");
+  *idx = nullptr;
+  *d2 = nullptr;
+  PCLMI_HIP(hipSetDevice(t->device));
+  float *d_q = nullptr;
+  uint64_t *d_off = nullptr;
+  int32_t *d_idx = nullptr;
+  float *d_d2 = nullptr;
+  uint64_t total = 0;
+  int rc = PCLMI_OK;
+  hipError_t e;
+  if ((e = hipMalloc(&d_q, (nq ? nq : 1) * q_stride_bytes)) != hipSuccess ||
+      (e = hipMalloc(&d_off, (nq + 1) * sizeof(uint64_t))) != hipSuccess ||
+      (nq && (e = hipMemcpy(d_q, q, nq * q_stride_bytes, hipMemcpyHostToDevice)) != hipSuccess)) {
+    rc = hip_fail(e, "query upload", __FILE__, __LINE__);
+  } else {
+    rc = pclmi_radius_dev(t, d_q, nq, q_stride_bytes, radius, max_nn, sorted, d_off, &d_idx, &d_d2, &total, nullptr);
+  }
+  if (rc == PCLMI_OK) {
+    int32_t *hi = (int32_t *)malloc((total ? total : 1) * sizeof(int32_t));
+    float *hd = (float *)malloc((total ? total : 1) * sizeof(float));
+    if (!hi || !hd) {
+      free(hi);
+      free(hd);
+      set_error("out of host memory for %llu radius results", (unsigned long long)total);
+      rc = PCLMI_ERR_OOM;
+    } else if ((e = hipMemcpy(offsets, d_off, (nq + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost)) != hipSuccess ||
+               (total && ((e = hipMemcpy(hi, d_idx, total * sizeof(int32_t), hipMemcpyDeviceToHost)) != hipSuccess ||
+                          (e = hipMemcpy(hd, d_d2, total * sizeof(float), hipMemcpyDeviceToHost)) != hipSuccess))) {
+      free(hi);
+      free(hd);
+      rc = hip_fail(e, "result download", __FILE__, __LINE__);
+    } else {
+      *idx = hi;
+      *d2 = hd;
+    }
+  }
+  if (d_q) (void)hipFree(d_q);
+  if (d_off) (void)hipFree(d_off);
+  if (d_idx) (void)hipFree(d_idx);
+  if (d_d2) (void)hipFree(d_d2);
+  return rc;
+}
+
+}  // extern "C"

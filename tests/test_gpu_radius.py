@@ -1,0 +1,113 @@
+"""GPU parity: pclmi_radius (HIP, through the C ABI) vs the CPU oracle, bit-exact CSR output."""
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from pcl_amd import capi as c
+    assert c.device_count() > 0, "no HIP device: the GPU tests must run on the MI355X box"
+    return c
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import pcl_oracle
+    return pcl_oracle
+
+
+def _same(g, o):
+    go, gi, gd = g
+    oo, oi, od = o
+    assert np.array_equal(go, oo), "offsets differ"
+    assert np.array_equal(gi, oi), "indices differ"
+    assert np.array_equal(gd.view(np.int32), od.view(np.int32)), "distances differ"
+
+
+@pytest.mark.parametrize("r", [0.01, 0.02, 0.04, 0.08])
+def test_uniform_1200_radii(capi, orc, r):
+    # recipe and radii of test/test_search.cpp:571-617,624-631
+    pts = util.uniform_cloud(1200, 7)
+    q = util.uniform_cloud(333, 8)
+    t = capi.Tree(pts)
+    for max_nn, srt in ((0, True), (0, False), (5, True), (5, False), (1, True), (5000, True)):
+        _same(t.radius(q, r, max_nn, srt), orc.radius_brute(pts, q, r, max_nn, srt))
+
+
+def test_grid_strict_radius_and_ties(capi, orc):
+    # 11^3 grid, radius 0.15 around grid points (test/kdtree/test_kdtree.cpp:100-131): strict <,
+    # many exactly equal distances -> (d2, index) order
+    pts = util.grid_cloud()
+    q = np.concatenate([pts[::5], np.array([[0, 0, 0], [0.05, 0.05, 0.05], [10, 10, 10]], np.float32)])
+    t = capi.Tree(pts)
+    for r in (0.15, 0.1, 0.2, 0.1000001):
+        for max_nn, srt in ((0, True), (0, False), (7, True), (7, False)):
+            _same(t.radius(q, r, max_nn, srt), orc.radius_brute(pts, q, r, max_nn, srt))
+    # the reference test's own check: every result within the radius, count equals brute force
+    off, idx, d2 = t.radius(np.zeros((1, 3), np.float32), 0.15)
+    brute = np.nonzero((pts * pts).sum(1, dtype=np.float32) < np.float32(0.15 * 0.15))[0]
+    assert sorted(idx.tolist()) == brute.tolist()
+
+
+def test_long_segments_and_everything_in_range(capi, orc):
+    # segments beyond the in-LDS sort (1024) and a radius that covers the whole cloud
+    pts = util.uniform_cloud(5000, 3)
+    q = util.uniform_cloud(40, 4)
+    t = capi.Tree(pts)
+    for r, max_nn, srt in ((0.5, 0, True), (0.5, 0, False), (3.0, 0, True), (3.0, 2000, False), (0.5, 1500, True),
+                           (1e20, 0, True)):
+        _same(t.radius(q, r, max_nn, srt), orc.radius_brute(pts, q, r, max_nn, srt))
+
+
+def test_empty_results_nan_queries_and_errors(capi, orc):
+    pts = util.uniform_cloud(3000, 5)
+    q = util.uniform_cloud(200, 6)
+    q[3] = np.nan
+    q[150, 0] = np.inf
+    t = capi.Tree(pts)
+    off, idx, d2 = t.radius(q, 0.05)
+    good = np.isfinite(q).all(axis=1)
+    oo, oi, od = orc.radius_brute(pts, q[good], 0.05)
+    cnt = np.diff(off)
+    assert cnt[3] == 0 and cnt[150] == 0
+    assert np.array_equal(cnt[good], np.diff(oo)) and np.array_equal(idx, oi) and np.array_equal(d2, od)
+    # zero / tiny radius: nothing is strictly inside
+    off, idx, d2 = t.radius(pts[:50], 0.0)
+    assert off.tolist() == [0] * 51 and len(idx) == 0
+    off, idx, d2 = t.radius(q[:0], 0.1)
+    assert off.tolist() == [0] and len(idx) == 0
+    e = capi.Tree(np.zeros((0, 3), np.float32))
+    off, idx, d2 = e.radius(q[:5], 1.0)
+    assert off.tolist() == [0] * 6
+    # duplicates of the query point itself are at distance 0 < r2
+    off, idx, d2 = t.radius(pts[:10], 1e-6)
+    assert np.diff(off).tolist() == [1] * 10 and idx.tolist() == list(range(10)) and not d2.any()
+
+
+@pytest.mark.parametrize("n,nq,mean_m", [(100_000, 20_000, 32), (250_000, 5_000, 200)])
+def test_large_vs_oracle_tree(capi, orc, n, nq, mean_m):
+    # BASELINE C3 scaled down: uniform cube [0,1024)^3, r tuned to `mean_m` expected neighbours
+    pts = util.uniform_cloud(n, 20260101, 0, 1024)
+    q = util.uniform_cloud(nq, 20260102, 0, 1024)
+    rho = n / 1024.0 ** 3
+    r = (mean_m * 3 / (4 * np.pi * rho)) ** (1 / 3)
+    t = capi.Tree(pts)
+    ot = orc.Tree(pts)
+    for max_nn, srt in ((0, True), (0, False), (10, True)):
+        g = t.radius(q, r, max_nn, srt)
+        _same(g, ot.radius(q, r, max_nn, srt, nthreads=8))
+    assert abs(np.diff(g[0]).mean() - 10) < 0.5
+
+
+def test_surface_like_cloud(capi, orc):
+    rng = np.random.default_rng(9)
+    n = 60_000
+    uv = rng.random((n, 2), dtype=np.float32) * 100
+    pts = np.stack([uv[:, 0], uv[:, 1], rng.integers(0, 4, n) * 7 + rng.normal(0, 0.05, n)], axis=1).astype(np.float32)
+    q = np.concatenate([pts[::40] + np.float32(0.2), rng.random((300, 3), dtype=np.float32) * 300 - 100]).astype(np.float32)
+    t = capi.Tree(pts)
+    _same(t.radius(q, 1.5), orc.Tree(pts).radius(q, 1.5, nthreads=8))
