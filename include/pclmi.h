@@ -146,6 +146,43 @@ int pclmi_correspondences_reciprocal(const pclmi_tree *target, const pclmi_tree 
                                      double max_distance, pclmi_correspondence *out,
                                      size_t *n_out);
 
+/* Correspondence rejection -----------------------------------------------------------
+ * Replace CorrespondenceRejector*::getRemainingCorrespondences
+ * (registration/include/pcl/registration/impl/correspondence_rejection_*.hpp).  `in` and `out` are
+ * host arrays (out has capacity n; in == out is not allowed); *n_out receives the remaining count.
+ * Where the reference sorts with std::sort (ties unspecified), ties are broken by index_query. */
+/* _distance.hpp:42-69: keep distance < max_distance^2 (setMaximumDistance squares,
+ * correspondence_rejection_distance.h:88); input order kept. */
+int pclmi_reject_distance(const pclmi_correspondence *in, size_t n, float max_distance,
+                          pclmi_correspondence *out, size_t *n_out);
+/* _median_distance.hpp:44-69: keep distance <= median * factor, median = the n/2-th smallest
+ * distance (*median, nullable).  The reference's loop reads the nth_element-permuted scratch array
+ * instead of the correspondences' own distances; the documented intent is implemented here. */
+int pclmi_reject_median(const pclmi_correspondence *in, size_t n, double factor,
+                        pclmi_correspondence *out, size_t *n_out, double *median);
+/* _one_to_one.hpp:42-67: sort by (index_match, distance), keep the nearest query of every match;
+ * output in that sorted order; negative matches are dropped. */
+int pclmi_reject_one_to_one(const pclmi_correspondence *in, size_t n, pclmi_correspondence *out,
+                            size_t *n_out);
+/* _trimmed.hpp:42-58: keep the max(floor(overlap_ratio * n), min_correspondences) smallest
+ * distances, sorted ascending; input returned unchanged when that is >= n. */
+int pclmi_reject_trimmed(const pclmi_correspondence *in, size_t n, float overlap_ratio,
+                         unsigned min_correspondences, pclmi_correspondence *out, size_t *n_out);
+/* _var_trimmed.hpp:44-107: trim factor = argmin of the FRMS curve over [min_ratio, max_ratio]
+ * (defaults 0.05, 0.95, lambda 0.95), keep distance < the int(n * factor)-th smallest distance;
+ * input order kept (documented intent, see pclmi_reject_median). */
+int pclmi_reject_var_trimmed(const pclmi_correspondence *in, size_t n, double min_ratio,
+                             double max_ratio, double lambda, pclmi_correspondence *out, size_t *n_out,
+                             double *trim_factor, double *trimmed_distance);
+/* _sample_consensus.hpp:44-110: RANSAC over SampleConsensusModelRegistration (seed 12345) on the
+ * pairs (src[index_query], tgt[index_match]); keeps the inliers of the best three-point model in
+ * input order, best_T = that model.  Keeps everything (best_T = identity) when no model is found. */
+int pclmi_reject_sample_consensus(const float *src, size_t n_src, size_t src_stride_bytes,
+                                  const float *tgt, size_t n_tgt, size_t tgt_stride_bytes,
+                                  const pclmi_correspondence *in, size_t n, double inlier_threshold,
+                                  int max_iterations, pclmi_correspondence *out, size_t *n_out,
+                                  float best_T[16]);
+
 /* Rigid transform from paired points ------------------------------------------------
  * Replaces TransformationEstimationSVD::estimateRigidTransformation
  * (registration/include/pcl/registration/impl/transformation_estimation_svd.hpp:81-168):

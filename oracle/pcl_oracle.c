@@ -835,6 +835,50 @@ int64_t orc_reject_trimmed(const orc_corr *in, int64_t n, float overlap, unsigne
   return n;
 }
 
+/* correspondence_rejection_var_trimmed.hpp:44-107.  optimizeInlierRatio sorts the distances and
+ * takes the argmin of FRMS_i = (1 / ratio_i^lambda)^2 * (1 / id_i) * (lower_sum + sorted[min_el + i])
+ * (elementwise, as the reference's Eigen expression reads - not a cumulative sum); the kept set is
+ * distance < sorted[int(n * factor)].  As in orc_reject_median the selection reads each
+ * correspondence's own distance (the reference's loop indexes the sorted scratch array instead). */
+int64_t orc_reject_var_trimmed(const orc_corr *in, int64_t n, double min_ratio, double max_ratio,
+                               double lambda, orc_corr *out, double *factor_out, double *trimmed_out) {
+  if (factor_out) *factor_out = 0.0;
+  if (trimmed_out) *trimmed_out = 0.0;
+  if (n == 0) return 0;
+  double *d = (double *)malloc((size_t)n * sizeof(double));
+  for (int64_t i = 0; i < n; ++i) d[i] = in[i].distance;
+  qsort(d, (size_t)n, sizeof(double), cmp_double);
+  unsigned nbr = (unsigned)n;
+  int min_el = (int)floor(min_ratio * nbr), max_el = (int)floor(max_ratio * nbr);
+  double lower_sum = 0.0;
+  for (int i = 0; i < min_el; ++i) lower_sum += d[i];
+  int min_index = 0;
+  double best = 0.0;
+  for (int i = 0; i < max_el - min_el; ++i) {
+    double id = (double)(min_el + 1 + i); /* LinSpaced(max_el - min_el, min_el + 1, max_el) */
+    double ratio = id / (double)nbr;
+    double deno = pow(ratio, lambda);
+    double inv = 1.0 / deno;
+    double frms = inv * inv * (1.0 / id) * (lower_sum + d[min_el + i]);
+    if (i == 0 || frms < best) {
+      best = frms;
+      min_index = i;
+    }
+  }
+  float opt_ratio = (float)(min_index + min_el) / (float)nbr;
+  double factor = (double)opt_ratio;
+  int64_t pos = (int64_t)(int)((double)n * factor);
+  if (pos >= n) pos = n - 1;
+  double trimmed = d[pos];
+  free(d);
+  if (factor_out) *factor_out = factor;
+  if (trimmed_out) *trimmed_out = trimmed;
+  int64_t c = 0;
+  for (int64_t i = 0; i < n; ++i)
+    if ((double)in[i].distance < trimmed) out[c++] = in[i];
+  return c;
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* boost::mt19937 seeded 12345 behind uniform_int<>(0, INT_MAX) (sac_model.h:87-97):
  * with a 32-bit engine and a 2^31 range Boost divides the engine output into buckets of

@@ -78,6 +78,16 @@ SIGNATURES = {
     "pclmi_correspondences_reciprocal": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t,
                                                    C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t,
                                                    C.c_double, C.c_void_p, C.POINTER(C.c_size_t)]),
+    "pclmi_reject_distance": (C.c_int, [C.c_void_p, C.c_size_t, C.c_float, C.c_void_p, C.POINTER(C.c_size_t)]),
+    "pclmi_reject_median": (C.c_int, [C.c_void_p, C.c_size_t, C.c_double, C.c_void_p, C.POINTER(C.c_size_t), c_f64p]),
+    "pclmi_reject_one_to_one": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t)]),
+    "pclmi_reject_trimmed": (C.c_int, [C.c_void_p, C.c_size_t, C.c_float, C.c_uint, C.c_void_p,
+                                       C.POINTER(C.c_size_t)]),
+    "pclmi_reject_var_trimmed": (C.c_int, [C.c_void_p, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_void_p,
+                                           C.POINTER(C.c_size_t), c_f64p, c_f64p]),
+    "pclmi_reject_sample_consensus": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
+                                                C.c_size_t, C.c_void_p, C.c_size_t, C.c_double, C.c_int, C.c_void_p,
+                                                C.POINTER(C.c_size_t), c_f32p]),
     "pclmi_estimate_rigid_svd": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
                                            C.c_size_t, C.c_void_p, C.c_size_t, c_f32p]),
     "pclmi_transform": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, c_f32p]),
@@ -230,6 +240,51 @@ def correspondences_reciprocal(target_tree, source_tree, src, tgt,
                                                 0 if si is None else len(si), t.ctypes.data, len(t), t.shape[1] * 4,
                                                 max_distance, out.ctypes.data, C.byref(n)))
     return out[: n.value].copy()
+
+
+def _rej(fn, corr, *args, extra=()):
+    c = np.ascontiguousarray(corr, CORR_DTYPE)
+    out = np.zeros(len(c), CORR_DTYPE)
+    n = C.c_size_t(0)
+    _check(fn(c.ctypes.data, len(c), *args, out.ctypes.data, C.byref(n), *extra))
+    return out[: n.value].copy()
+
+
+def reject_distance(corr, max_distance):
+    return _rej(load_library().pclmi_reject_distance, corr, max_distance)
+
+
+def reject_median(corr, factor=1.0):
+    med = C.c_double(0)
+    out = _rej(load_library().pclmi_reject_median, corr, factor, extra=(C.byref(med),))
+    return out, med.value
+
+
+def reject_one_to_one(corr):
+    return _rej(load_library().pclmi_reject_one_to_one, corr)
+
+
+def reject_trimmed(corr, overlap=0.5, min_corr=0):
+    return _rej(load_library().pclmi_reject_trimmed, corr, overlap, min_corr)
+
+
+def reject_var_trimmed(corr, min_ratio=0.05, max_ratio=0.95, lam=0.95):
+    f, d = C.c_double(0), C.c_double(0)
+    out = _rej(load_library().pclmi_reject_var_trimmed, corr, min_ratio, max_ratio, lam, extra=(C.byref(f), C.byref(d)))
+    return out, f.value, d.value
+
+
+def reject_sample_consensus(src, tgt, corr, inlier_threshold=0.05, max_iterations=2**31 - 1):
+    s, t = _pts(src), _pts(tgt)
+    c = np.ascontiguousarray(corr, CORR_DTYPE)
+    out = np.zeros(len(c), CORR_DTYPE)
+    n = C.c_size_t(0)
+    T = np.zeros(16, np.float32)
+    _check(load_library().pclmi_reject_sample_consensus(s.ctypes.data, len(s), s.shape[1] * 4, t.ctypes.data, len(t),
+                                                        t.shape[1] * 4, c.ctypes.data, len(c), inlier_threshold,
+                                                        max_iterations, out.ctypes.data, C.byref(n),
+                                                        T.ctypes.data_as(c_f32p)))
+    return out[: n.value].copy(), T.reshape(4, 4)
 
 
 def estimate_rigid_svd(src, tgt, src_idx=None, tgt_idx=None):

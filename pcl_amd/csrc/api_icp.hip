@@ -11,33 +11,6 @@ using namespace pclmi;
 
 namespace {
 
-// minimal RAII device buffer
-template <typename T>
-struct DevBuf {
-  T *p = nullptr;
-  size_t n = 0;
-  ~DevBuf() { reset(); }
-  void reset() {
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    n = 0;
-  }
-  int alloc(size_t count) {
-    reset();
-    if (count == 0) count = 1;
-    hipError_t e = hipMalloc(&p, count * sizeof(T));
-    if (e != hipSuccess) return hip_fail(e, "hipMalloc", __FILE__, __LINE__);
-    n = count;
-    return PCLMI_OK;
-  }
-};
-
-#define RC(call)              \
-  do {                        \
-    int rc_ = (call);         \
-    if (rc_) return rc_;      \
-  } while (0)
-
 bool is_identity(const float *T) {
   for (int i = 0; i < 16; ++i)
     if (T[i] != ((i % 5 == 0) ? 1.f : 0.f)) return false;
@@ -368,52 +341,35 @@ int pclmi_icp_end(pclmi_icp_ctx *c, float *aligned) {
 // no model was found (the caller then keeps all pairs, icp.hpp:128-132).
 namespace {
 
-struct RansacScratch {
-  DevBuf<int> ids, pair_src, pair_slot, pair_tgt, num;
-  DevBuf<unsigned char> keep, flags;
-  DevBuf<int> tgt_of_orig;
+// Generic core: pairs (src[sidx[i]], tgt[tidx[i]]), i < cnt.  On success *have = true, Tbest holds the best
+// three-point model, d_flags the inlier mask of selectWithinDistance and *n_inliers its population.
+struct RansacDev {
   DevBuf<unsigned int> count;
   DevBuf<float4> six;
-  DevBuf<unsigned char> tmp;
-  size_t tmp_bytes = 0;
+  DevBuf<double> partials, sums;
+  int init(size_t n) {
+    if (count.p) return PCLMI_OK;
+    RC(count.alloc(1));
+    RC(six.alloc(6));
+    RC(partials.alloc((size_t)pair_reduce_blocks(n) * PCLMI_ICP_NSUMS));
+    RC(sums.alloc(PCLMI_ICP_NSUMS));
+    return PCLMI_OK;
+  }
 };
 
-int ransac_icp(pclmi_icp_ctx *c, RansacScratch &rs, const pclmi_icp_params *p, int64_t *n_inliers,
-               double sums_out[PCLMI_ICP_NSUMS]) {
-  *n_inliers = -1;
-  const size_t n = c->n;
-  hipStream_t s = c->stream;
-  const float4 *cloud = (const float4 *)c->tree->d_cloud;
-  if (!rs.ids.p) {
-    RC(rs.ids.alloc(n));
-    RC(rs.pair_src.alloc(n));
-    RC(rs.pair_slot.alloc(n));
-    RC(rs.pair_tgt.alloc(n));
-    RC(rs.num.alloc(1));
-    RC(rs.keep.alloc(n));
-    RC(rs.flags.alloc(n));
-    RC(rs.tgt_of_orig.alloc(n));
-    RC(rs.count.alloc(1));
-    RC(rs.six.alloc(6));
-    launch_iota(rs.ids.p, n, s);
-    size_t need = 0;
-    RC(select_flagged(rs.ids.p, rs.keep.p, n, rs.pair_src.p, rs.num.p, nullptr, 0, &need, s));
-    rs.tmp_bytes = need + 256;
-    RC(rs.tmp.alloc(rs.tmp_bytes));
-  }
-  // kept pairs in ORIGINAL source order (the order the reference's index lists have)
-  launch_corr_flags(c->nn.p, c->pts.p, cloud, c->order.p, n, c->last_thr2, rs.tgt_of_orig.p, rs.keep.p, s);
-  RC(select_flagged(rs.ids.p, rs.keep.p, n, rs.pair_src.p, rs.num.p, rs.tmp.p, rs.tmp_bytes, nullptr, s));
-  int cnt = 0;
-  PCLMI_HIP(hipMemcpyAsync(&cnt, rs.num.p, 4, hipMemcpyDeviceToHost, s));
-  PCLMI_HIP(hipStreamSynchronize(s));
+int ransac_core(RansacDev &rd, const float4 *src, const int *sidx, const float4 *tgt, const int *tidx, int cnt,
+                double inlier_threshold, int max_iterations, unsigned char *d_flags, hipStream_t s, bool *have_out,
+                float Tbest[16], unsigned int *n_inliers, int *trials) {
+  *have_out = false;
+  *n_inliers = 0;
+  if (trials) *trials = 0;
+  set_identity(Tbest);
   if (cnt < 3) return PCLMI_OK;  // getSamples clears the selection, computeModel fails (ransac.hpp:72-76)
-  launch_gather_int(c->inv.p, rs.pair_src.p, cnt, rs.pair_slot.p, s);
-  launch_gather_int(rs.tgt_of_orig.p, rs.pair_src.p, cnt, rs.pair_tgt.p, s);
+  RC(rd.init((size_t)cnt));
   // sample_dist_thresh_ (sac_model_registration.h:257-279)
   double m[PCLMI_ICP_NSUMS];
-  launch_moment_reduce(c->pts.p, rs.pair_slot.p, cnt, c->partials.p, c->sums.p, s);
-  PCLMI_HIP(hipMemcpyAsync(m, c->sums.p, sizeof(m), hipMemcpyDeviceToHost, s));
+  launch_moment_reduce(src, sidx, cnt, rd.partials.p, rd.sums.p, s);
+  PCLMI_HIP(hipMemcpyAsync(m, rd.sums.p, sizeof(m), hipMemcpyDeviceToHost, s));
   PCLMI_HIP(hipStreamSynchronize(s));
   const double inv_n = 1.0 / m[9];
   double a[9];
@@ -431,14 +387,12 @@ int ransac_icp(pclmi_icp_ctx *c, RansacScratch &rs, const pclmi_icp_params *p, i
   std::mt19937 gen(12345u);  // boost::mt19937 seed 12345 (sac_model.h:95); rnd() == gen() >> 1
   std::vector<int> shuf(cnt);
   for (int i = 0; i < cnt; ++i) shuf[i] = i;
-  const double thresh = p->ransac_outlier_threshold * p->ransac_outlier_threshold;
+  const double thresh = inlier_threshold * inlier_threshold;
   int iterations = 0, best = -INT32_MAX;
   double k = 1.0;
   unsigned skipped = 0;
-  const unsigned max_skip = (unsigned)p->ransac_iterations * 10u;
+  const unsigned max_skip = (unsigned)std::min<long long>((long long)max_iterations * 10, 0xffffffffll);
   bool have = false;
-  float Tbest[16];
-  set_identity(Tbest);
   float4 h6[6];
   while (iterations < k && skipped < max_skip) {
     bool good = false;
@@ -449,8 +403,8 @@ int ransac_icp(pclmi_icp_ctx *c, RansacScratch &rs, const pclmi_icp_params *p, i
         std::swap(shuf[i], shuf[i + (int)(r % (uint32_t)(cnt - i))]);  // drawIndexSample (:401-412)
       }
       for (int i = 0; i < 3; ++i) sel[i] = shuf[i];
-      launch_gather_points(c->pts.p, rs.pair_slot.p, cloud, rs.pair_tgt.p, sel, rs.six.p, s);
-      PCLMI_HIP(hipMemcpyAsync(h6, rs.six.p, sizeof(h6), hipMemcpyDeviceToHost, s));
+      launch_gather_points(src, sidx, tgt, tidx, sel, rd.six.p, s);
+      PCLMI_HIP(hipMemcpyAsync(h6, rd.six.p, sizeof(h6), hipMemcpyDeviceToHost, s));
       PCLMI_HIP(hipStreamSynchronize(s));
       auto sq = [](const float4 &u, const float4 &v) {
         const float dx = u.x - v.x, dy = u.y - v.y, dz = u.z - v.z;
@@ -481,9 +435,8 @@ int ransac_icp(pclmi_icp_ctx *c, RansacScratch &rs, const pclmi_icp_params *p, i
       continue;
     }
     unsigned int inl = 0;
-    launch_count_within(c->pts.p, rs.pair_slot.p, cloud, rs.pair_tgt.p, cnt, make_xf(T), thresh, rs.count.p,
-                        nullptr, s);
-    PCLMI_HIP(hipMemcpyAsync(&inl, rs.count.p, 4, hipMemcpyDeviceToHost, s));
+    launch_count_within(src, sidx, tgt, tidx, cnt, make_xf(T), thresh, rd.count.p, nullptr, s);
+    PCLMI_HIP(hipMemcpyAsync(&inl, rd.count.p, 4, hipMemcpyDeviceToHost, s));
     PCLMI_HIP(hipStreamSynchronize(s));
     if ((int)inl > best) {
       best = (int)inl;
@@ -496,16 +449,68 @@ int ransac_icp(pclmi_icp_ctx *c, RansacScratch &rs, const pclmi_icp_params *p, i
       k = std::log(1.0 - 0.99) / std::log(p_no);  // ransac.hpp:102-107
     }
     ++iterations;
-    if (iterations > p->ransac_iterations) break;
+    if (iterations > max_iterations) break;
   }
+  if (trials) *trials = iterations;
   if (!have) return PCLMI_OK;
-  // selectWithinDistance with the best model, then the sums of the inlier pairs
+  // selectWithinDistance with the best model
   unsigned int inl = 0;
-  launch_count_within(c->pts.p, rs.pair_slot.p, cloud, rs.pair_tgt.p, cnt, make_xf(Tbest), thresh, rs.count.p,
-                      rs.flags.p, s);
+  launch_count_within(src, sidx, tgt, tidx, cnt, make_xf(Tbest), thresh, rd.count.p, d_flags, s);
+  PCLMI_HIP(hipMemcpyAsync(&inl, rd.count.p, 4, hipMemcpyDeviceToHost, s));
+  PCLMI_HIP(hipStreamSynchronize(s));
+  *n_inliers = inl;
+  *have_out = true;
+  return PCLMI_OK;
+}
+
+struct RansacScratch {
+  DevBuf<int> ids, pair_src, pair_slot, pair_tgt, num;
+  DevBuf<unsigned char> keep, flags;
+  DevBuf<int> tgt_of_orig;
+  DevBuf<unsigned char> tmp;
+  size_t tmp_bytes = 0;
+  RansacDev rd;
+};
+
+int ransac_icp(pclmi_icp_ctx *c, RansacScratch &rs, const pclmi_icp_params *p, int64_t *n_inliers,
+               double sums_out[PCLMI_ICP_NSUMS]) {
+  *n_inliers = -1;
+  const size_t n = c->n;
+  hipStream_t s = c->stream;
+  const float4 *cloud = (const float4 *)c->tree->d_cloud;
+  if (!rs.ids.p) {
+    RC(rs.ids.alloc(n));
+    RC(rs.pair_src.alloc(n));
+    RC(rs.pair_slot.alloc(n));
+    RC(rs.pair_tgt.alloc(n));
+    RC(rs.num.alloc(1));
+    RC(rs.keep.alloc(n));
+    RC(rs.flags.alloc(n));
+    RC(rs.tgt_of_orig.alloc(n));
+    launch_iota(rs.ids.p, n, s);
+    size_t need = 0;
+    RC(select_flagged(rs.ids.p, rs.keep.p, n, rs.pair_src.p, rs.num.p, nullptr, 0, &need, s));
+    rs.tmp_bytes = need + 256;
+    RC(rs.tmp.alloc(rs.tmp_bytes));
+  }
+  // kept pairs in ORIGINAL source order (the order the reference's index lists have)
+  launch_corr_flags(c->nn.p, c->pts.p, cloud, c->order.p, n, c->last_thr2, rs.tgt_of_orig.p, rs.keep.p, s);
+  RC(select_flagged(rs.ids.p, rs.keep.p, n, rs.pair_src.p, rs.num.p, rs.tmp.p, rs.tmp_bytes, nullptr, s));
+  int cnt = 0;
+  PCLMI_HIP(hipMemcpyAsync(&cnt, rs.num.p, 4, hipMemcpyDeviceToHost, s));
+  PCLMI_HIP(hipStreamSynchronize(s));
+  if (cnt < 3) return PCLMI_OK;
+  launch_gather_int(c->inv.p, rs.pair_src.p, cnt, rs.pair_slot.p, s);
+  launch_gather_int(rs.tgt_of_orig.p, rs.pair_src.p, cnt, rs.pair_tgt.p, s);
+  bool have = false;
+  float Tbest[16];
+  unsigned int inl = 0;
+  RC(ransac_core(rs.rd, c->pts.p, rs.pair_slot.p, cloud, rs.pair_tgt.p, cnt, p->ransac_outlier_threshold,
+                 p->ransac_iterations, rs.flags.p, s, &have, Tbest, &inl, nullptr));
+  if (!have) return PCLMI_OK;
+  // the sums of the inlier pairs, for the refit (icp.hpp:171 on the *_good index lists)
   launch_pair_reduce(c->pts.p, rs.pair_slot.p, cloud, rs.pair_tgt.p, rs.flags.p, cnt, c->origin, c->partials.p,
                      c->sums.p, s);
-  PCLMI_HIP(hipMemcpyAsync(&inl, rs.count.p, 4, hipMemcpyDeviceToHost, s));
   PCLMI_HIP(hipMemcpyAsync(sums_out, c->sums.p, PCLMI_ICP_NSUMS * sizeof(double), hipMemcpyDeviceToHost, s));
   PCLMI_HIP(hipStreamSynchronize(s));
   *n_inliers = inl;
@@ -583,6 +588,61 @@ int pclmi_icp_align(const pclmi_icp_params *p, const pclmi_tree *target, const f
   }
   int rc2 = pclmi_icp_end(c, aligned);
   return rc ? rc : rc2;
+}
+
+// CorrespondenceRejectorSampleConsensus::getRemainingCorrespondences
+// (registration/include/pcl/registration/impl/correspondence_rejection_sample_consensus.hpp:44-110)
+int pclmi_reject_sample_consensus(const float *src, size_t n_src, size_t src_stride_bytes, const float *tgt,
+                                  size_t n_tgt, size_t tgt_stride_bytes, const pclmi_correspondence *in, size_t n,
+                                  double inlier_threshold, int max_iterations, pclmi_correspondence *out,
+                                  size_t *n_out, float best_T[16]) {
+  PCLMI_CHECK(n_out && best_T, PCLMI_ERR_INVALID, "NULL argument");
+  *n_out = 0;
+  set_identity(best_T);
+  PCLMI_CHECK(n == 0 || (in && out && src && tgt), PCLMI_ERR_INVALID, "NULL argument");
+  PCLMI_CHECK(src_stride_bytes >= 12 && src_stride_bytes % 4 == 0 && tgt_stride_bytes >= 12 &&
+                  tgt_stride_bytes % 4 == 0,
+              PCLMI_ERR_INVALID, "bad stride");
+  PCLMI_CHECK(n < ((size_t)1 << 31), PCLMI_ERR_UNSUPPORTED, "more than 2^31-1 correspondences");
+  PCLMI_CHECK(pclmi_device_count() > 0, PCLMI_ERR_NO_DEVICE, "no HIP device visible: libpclmi has no CPU fallback");
+  auto keep_all = [&]() {  // computeModel failed or < 3 inliers (:78-95)
+    std::memcpy(out, in, n * sizeof(pclmi_correspondence));
+    *n_out = n;
+    return PCLMI_OK;
+  };
+  if (n < 3) return n ? keep_all() : PCLMI_OK;
+  std::vector<int32_t> si(n), ti(n);
+  for (size_t i = 0; i < n; ++i) {
+    si[i] = in[i].index_query;
+    ti[i] = in[i].index_match;
+    PCLMI_CHECK(si[i] >= 0 && (size_t)si[i] < n_src && ti[i] >= 0 && (size_t)ti[i] < n_tgt, PCLMI_ERR_INVALID,
+                "correspondence %zu (%d -> %d) is outside the clouds", i, si[i], ti[i]);
+  }
+  DevBuf<float4> ds, dt;
+  RC(upload_packed(src, n_src, src_stride_bytes, nullptr, 0, ds, nullptr));
+  RC(upload_packed(tgt, n_tgt, tgt_stride_bytes, nullptr, 0, dt, nullptr));
+  DevBuf<int> dsi, dti;
+  DevBuf<unsigned char> flags;
+  RC(dsi.alloc(n));
+  RC(dti.alloc(n));
+  RC(flags.alloc(n));
+  PCLMI_HIP(hipMemcpy(dsi.p, si.data(), n * 4, hipMemcpyHostToDevice));
+  PCLMI_HIP(hipMemcpy(dti.p, ti.data(), n * 4, hipMemcpyHostToDevice));
+  RansacDev rd;
+  bool have = false;
+  unsigned int inl = 0;
+  float T[16];
+  RC(ransac_core(rd, ds.p, dsi.p, dt.p, dti.p, (int)n, inlier_threshold, max_iterations, flags.p, nullptr, &have, T,
+                 &inl, nullptr));
+  if (!have || inl < 3) return keep_all();
+  std::vector<unsigned char> hf(n);
+  PCLMI_HIP(hipMemcpy(hf.data(), flags.p, n, hipMemcpyDeviceToHost));
+  size_t c = 0;
+  for (size_t i = 0; i < n; ++i)
+    if (hf[i]) out[c++] = in[i];
+  *n_out = c;
+  std::memcpy(best_T, T, sizeof(T));  // the best sample's model coefficients (:103-108)
+  return PCLMI_OK;
 }
 
 int pclmi_fitness_score(const pclmi_tree *target, const float *src, size_t n_src, size_t stride_bytes,

@@ -40,6 +40,33 @@ struct TimingScope {
   ~TimingScope();
 };
 
+// minimal RAII device buffer
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  ~DevBuf() { reset(); }
+  void reset() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  int alloc(size_t count) {
+    reset();
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc(&p, count * sizeof(T));
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc", __FILE__, __LINE__);
+    n = count;
+    return PCLMI_OK;
+  }
+};
+
+#define RC(call)              \
+  do {                        \
+    int rc_ = (call);         \
+    if (rc_) return rc_;      \
+  } while (0)
+
 // ---- device tree ------------------------------------------------------------------------
 // Left-balanced bucket kd-tree in implicit (heap) order: node ids 1 .. 2M-1, children of i
 // are 2i and 2i+1, ids >= M are leaves (leaf number = id - M).  See DESIGN.md "Data layout".

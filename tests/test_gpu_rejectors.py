@@ -1,0 +1,108 @@
+"""GPU parity of the correspondence rejectors (through the C ABI) vs golden vectors and the oracle."""
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from pcl_amd import capi as c
+    assert c.device_count() > 0, "no HIP device: the GPU tests must run on the MI355X box"
+    return c
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import pcl_oracle
+    return pcl_oracle
+
+
+def test_bun_rejectors_golden(capi, orc):
+    # test/registration/test_registration_api.cpp:100-347 + test_registration_api_data.h
+    api = util.golden("registration_api.json")
+    src, tgt = util.bun0(), util.bun4()
+    corr = capi.correspondences(capi.Tree(tgt), src)
+    rd = capi.reject_distance(corr, api["rej_dist_max_dist"])
+    exp = np.array(api["correspondences_dist"])
+    assert rd["index_query"].tolist() == exp[:, 0].tolist() and rd["index_match"].tolist() == exp[:, 1].tolist()
+    oo = capi.reject_one_to_one(corr)
+    exp = np.array(api["correspondences_one_to_one"])
+    assert oo["index_query"].tolist() == exp[:, 0].tolist() and oo["index_match"].tolist() == exp[:, 1].tolist()
+    tr = capi.reject_trimmed(corr, api["rej_trimmed_overlap"])
+    exp = np.array(api["correspondences_trimmed"])
+    assert tr["index_query"].tolist() == exp[:, 0].tolist() and tr["index_match"].tolist() == exp[:, 1].tolist()
+    sac, T = capi.reject_sample_consensus(src, tgt, corr, api["rej_sac_max_dist"], api["rej_sac_max_iter"])
+    exp = np.array(api["correspondences_sac"])
+    assert sac["index_match"].tolist() == exp[:, 1].tolist()  # the reference test checks index_match
+    assert np.allclose(T, np.array(api["transform_from_SAC"]), atol=1e-4)
+    md, med = capi.reject_median(corr, 0.5)
+    omd, omed = orc.reject_median(corr, 0.5)
+    assert med == omed and np.array_equal(md, omd)
+    vt, f, d = capi.reject_var_trimmed(corr)
+    ovt, of, od = orc.reject_var_trimmed(corr)
+    assert (f, d) == (of, od) and np.array_equal(vt, ovt)
+
+
+def _random_corr(n, seed, n_match):
+    rng = np.random.default_rng(seed)
+    from pcl_amd.capi import CORR_DTYPE
+    c = np.zeros(n, CORR_DTYPE)
+    c["index_query"] = rng.permutation(n).astype(np.int32)
+    c["index_match"] = rng.integers(-2, n_match, n).astype(np.int32)
+    c["distance"] = (rng.random(n, dtype=np.float32) ** 2).astype(np.float32)
+    c["distance"][rng.integers(0, n, n // 10)] = np.float32(0.25)  # exact ties
+    return c
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 1000, 200_000])
+def test_rejectors_vs_oracle_random(capi, orc, n):
+    c = _random_corr(n, 17 + n, max(1, n // 3))
+    assert np.array_equal(capi.reject_distance(c, 0.5), orc.reject_distance(c, 0.5))
+    for factor in (0.5, 1.0, 2.0):
+        g, gm = capi.reject_median(c, factor)
+        o, om = orc.reject_median(c, factor)
+        assert gm == om and np.array_equal(g, o)
+    assert np.array_equal(capi.reject_one_to_one(c), orc.reject_one_to_one(c))
+    for ov, mc in ((0.5, 0), (0.9, 0), (0.1, 5), (1.0, 0), (0.0, 0)):
+        assert np.array_equal(capi.reject_trimmed(c, ov, mc), orc.reject_trimmed(c, ov, mc))
+    for a, b, lam in ((0.05, 0.95, 0.95), (0.2, 0.6, 0.5)):
+        g, gf, gd = capi.reject_var_trimmed(c, a, b, lam)
+        o, of, od = orc.reject_var_trimmed(c, a, b, lam)
+        assert (gf, gd) == (of, od) and np.array_equal(g, o)
+
+
+def test_rejectors_empty(capi):
+    from pcl_amd.capi import CORR_DTYPE
+    e = np.zeros(0, CORR_DTYPE)
+    assert len(capi.reject_distance(e, 1.0)) == 0 and len(capi.reject_one_to_one(e)) == 0
+    assert len(capi.reject_trimmed(e)) == 0 and len(capi.reject_median(e)[0]) == 0
+    assert len(capi.reject_var_trimmed(e)[0]) == 0
+
+
+def test_sample_consensus_rejector_vs_oracle(capi, orc):
+    # a planted rigid motion + 25 % outlier pairs
+    rng = np.random.default_rng(23)
+    n = 5000
+    src = (rng.random((n, 3), dtype=np.float32) * 10).astype(np.float32)
+    th = np.deg2rad(20)
+    T0 = np.eye(4, dtype=np.float32)
+    T0[:2, :2] = [[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]]
+    T0[:3, 3] = [1, -2, 0.5]
+    tgt = orc.transform(src, T0) + rng.normal(0, 0.005, (n, 3)).astype(np.float32)
+    from pcl_amd.capi import CORR_DTYPE
+    c = np.zeros(n, CORR_DTYPE)
+    c["index_query"] = np.arange(n)
+    c["index_match"] = np.arange(n)
+    bad = rng.permutation(n)[: n // 4]
+    c["index_match"][bad] = rng.integers(0, n, len(bad))
+    g, T = capi.reject_sample_consensus(src, tgt, c, 0.05, 1000)
+    pos, To, trials = orc.ransac_registration(src, tgt, c["index_query"], c["index_match"], 0.05, 1000)
+    assert pos is not None and np.array_equal(g, c[pos])
+    assert np.abs(T - To).max() < 1e-4  # three-point model: fp64 solve vs the oracle's fp32 solve
+    assert len(g) >= (3 * n) // 4 - 50
+    # no model: fewer than 3 pairs keep everything
+    g2, T2 = capi.reject_sample_consensus(src, tgt, c[:2], 0.05, 10)
+    assert np.array_equal(g2, c[:2]) and np.array_equal(T2, np.eye(4, dtype=np.float32))
