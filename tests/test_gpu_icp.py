@@ -235,3 +235,16 @@ def test_sharded_steps_equal_single_shard(capi, orc):
     o1 = one.end()
     oa, ob = a.end(), b.end()
     assert np.array_equal(o1, np.concatenate([oa, ob]))
+
+
+def test_sharded_driver_single_rank_equals_icp_align(capi, orc):
+    """pcl_amd/sharded.py on one rank (no process group) == pclmi_icp_align with RANSAC off."""
+    from pcl_amd import sharded
+    src, tgt = util.bun0(), util.bun4()
+    tt = capi.Tree(tgt)
+    p = capi.icp_default_params()
+    p.max_iterations, p.max_correspondence_distance, p.ransac_iterations = 20, 0.05, 0
+    rc, T, out, st = capi.icp_align(tt, src, p)
+    rc2, T2, out2, it, ok, pairs = sharded.icp_align_gpu_sharded(tt, src, p)
+    assert rc == rc2 == 0 and ok and it == st.iterations and pairs == st.last_correspondences
+    assert np.array_equal(T, T2) and np.array_equal(out, out2)
