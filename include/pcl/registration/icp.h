@@ -1,0 +1,99 @@
+// pcl/registration/icp.h - pcl::IterativeClosestPoint<PointSource, PointTarget>
+// (registration/include/pcl/registration/icp.h:87-136, impl/icp.hpp:44-211).
+// The whole correspondence loop - 1-NN, threshold, optional RANSAC rejection, centroid /
+// cross-covariance reduction, SVD, transform, convergence tests - runs in ONE library call
+// (pclmi_icp_align); the source cloud crosses PCIe once in, once out.
+#ifndef PCLMI_FACADE_REGISTRATION_ICP_H_
+#define PCLMI_FACADE_REGISTRATION_ICP_H_
+
+#include <pcl/registration/registration.h>
+#include <pcl/registration/transformation_estimation_svd.h>
+
+namespace pcl {
+
+template <typename PointSource, typename PointTarget>
+class IterativeClosestPoint : public Registration<PointSource, PointTarget> {
+  typedef Registration<PointSource, PointTarget> Base;
+
+ public:
+  typedef typename Base::PointCloudSource PointCloudSource;
+  using Base::reg_name_;
+  using Base::getClassName;
+  using Base::tree_;
+  using Base::nr_iterations_;
+  using Base::max_iterations_;
+  using Base::ransac_iterations_;
+  using Base::final_transformation_;
+  using Base::transformation_;
+  using Base::previous_transformation_;
+  using Base::transformation_epsilon_;
+  using Base::euclidean_fitness_epsilon_;
+  using Base::corr_dist_threshold_;
+  using Base::inlier_threshold_;
+  using Base::converged_;
+  using Base::min_number_correspondences_;
+  using Base::transformation_estimation_;
+
+  IterativeClosestPoint() {  // icp.h:99-106
+    reg_name_ = "IterativeClosestPoint";
+    ransac_iterations_ = 1000;
+    transformation_estimation_.reset(new pcl::registration::TransformationEstimationSVD<PointSource, PointTarget>);
+    svd_estimation_ = transformation_estimation_.get();
+  }
+
+  // statistics of the last align()
+  int getNumberOfIterations() const { return nr_iterations_; }
+  const pclmi_icp_stats &getLastStats() const { return stats_; }
+
+ protected:
+  void computeTransformation(PointCloudSource &output, const Matrix4f &guess) override {
+    nr_iterations_ = 0;
+    std::memset(&stats_, 0, sizeof(stats_));
+    if (transformation_estimation_.get() != svd_estimation_) {
+      PCL_ERROR("[pcl::%s::computeTransformation] only TransformationEstimationSVD is supported by the device loop\n",
+                getClassName().c_str());
+      return;
+    }
+    if (!tree_->getDeviceTree() || output.points.empty()) return;
+    pclmi_icp_params p;
+    pclmi_icp_default_params(&p);
+    p.max_iterations = max_iterations_;
+    p.ransac_iterations = ransac_iterations_;
+    p.transformation_epsilon = transformation_epsilon_;
+    p.euclidean_fitness_epsilon = euclidean_fitness_epsilon_;
+    p.max_correspondence_distance = corr_dist_threshold_;
+    p.ransac_outlier_threshold = inlier_threshold_;
+    p.min_correspondences = min_number_correspondences_;
+    std::vector<float> aligned(output.points.size() * 4);
+    // `output` already holds input[indices] (Registration::align); the library sets w = 1, applies the
+    // guess (icp.hpp:60-66) and iterates
+    const int rc = pclmi_icp_align(&p, tree_->getDeviceTree(), reinterpret_cast<const float *>(output.points.data()),
+                                   output.points.size(), sizeof(PointSource), guess.isIdentity() ? nullptr : guess.data(),
+                                   final_transformation_.data(), aligned.data(), &stats_);
+    nr_iterations_ = stats_.iterations;
+    converged_ = stats_.converged != 0;
+    if (rc == PCLMI_ERR_NOT_ENOUGH) {  // icp.hpp:103-108
+      PCL_ERROR("[pcl::%s::computeTransformation] Not enough correspondences found. Relax your threshold parameters.\n",
+                getClassName().c_str());
+    } else if (rc != PCLMI_OK) {
+      PCL_ERROR("[pcl::%s::computeTransformation] %s\n", getClassName().c_str(), pclmi_last_error());
+      return;
+    }
+    for (size_t i = 0; i < output.points.size(); ++i) {
+      output.points[i].x = aligned[i * 4 + 0];
+      output.points[i].y = aligned[i * 4 + 1];
+      output.points[i].z = aligned[i * 4 + 2];
+      output.points[i].data[3] = 1.0f;  // registration.hpp:152-163
+    }
+    PCL_DEBUG("[pcl::%s::computeTransformation] %d iterations, %d correspondences (%d after rejection), converged %d, "
+              "transform delta %g, fitness delta %g\n", getClassName().c_str(), stats_.iterations,
+              stats_.last_correspondences, stats_.last_inliers, stats_.converged, stats_.transform_delta,
+              stats_.fitness_delta);
+  }
+
+  const void *svd_estimation_;
+  pclmi_icp_stats stats_;
+};
+
+}  // namespace pcl
+#endif

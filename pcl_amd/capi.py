@@ -104,11 +104,34 @@ SIGNATURES = {
 }
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so with the same
+    SONAME (libamdhip64.so.7) as the system ROCm one libpclmi.so is linked to; whichever is loaded first
+    serves both.  torch does not find its GPUs when the system copy got in first, so when torch is
+    installed its copy is loaded here (without importing torch); processes without torch use /opt/rocm."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec and spec.origin:
+        rt = Path(spec.origin).parent / "lib" / "libamdhip64.so"
+        if rt.exists():
+            try:
+                C.CDLL(str(rt), mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+
+
 def load_library(path=None):
     """Loads libpclmi.so; raises if it has not been built (no fallback of any kind)."""
     global _LIB
     if _LIB is not None:
         return _LIB
+    _share_hip_runtime_with_torch()
     p = Path(path) if path else LIB_PATH
     if not p.exists():
         raise PclmiError(2, "%s is missing - run `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -26,6 +26,16 @@ def allreduce_sums(local_sums, group=None):
     return local_sums
 
 
+def mat4_mul_f32(A, B):
+    """A * B in fp32 with the library's summation order (icp.hpp:177 final = T * final)."""
+    A = np.asarray(A, np.float32)
+    B = np.asarray(B, np.float32)
+    out = np.zeros((4, 4), np.float32)
+    for k in range(4):
+        out = (out + A[:, k:k + 1] * B[k:k + 1, :]).astype(np.float32)
+    return out
+
+
 def converged(iteration, T, T_prev, fitness_delta, params):
     """icp.hpp:193-196."""
     tdelta = float(np.abs(T - T_prev).astype(np.float32).sum(dtype=np.float32))
@@ -52,7 +62,7 @@ def icp_align_sharded(step_fn, set_transform_fn, params, guess=None, group=None)
             return 6, final_T, it, False, pairs
         T = capi.icp_solve(h)
         set_transform_fn(T)
-        final_T = (T @ final_T).astype(np.float32)  # icp.hpp:177
+        final_T = mat4_mul_f32(T, final_T)  # icp.hpp:177
         it += 1
         n_points = h[18] if h[18] > 0 else 1.0
         done = converged(it, T, T_prev, h[17] / n_points, params)

@@ -1,0 +1,397 @@
+// test_facade.cpp - the reference's own tests for the kNN / ICP path, re-expressed against the
+// C++ facade in include/pcl/ (which calls libpclmi.so -> MI355X).  No gtest: a tiny EXPECT macro.
+// Mirrors test/kdtree/test_kdtree.cpp:100-166,221-268,336-398, test/search/test_kdtree.cpp:127-196,
+// test/registration/test_registration_api.cpp:62-347 and test/registration/test_registration.cpp:154-188.
+// usage: test_facade <tests/golden dir>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <set>
+#include <sstream>
+#include <string>
+
+#include <pcl/common/time.h>
+#include <pcl/common/transforms.h>
+#include <pcl/kdtree/kdtree_flann.h>
+#include <pcl/point_types.h>
+#include <pcl/registration/correspondence_estimation.h>
+#include <pcl/registration/correspondence_rejection_distance.h>
+#include <pcl/registration/correspondence_rejection_median_distance.h>
+#include <pcl/registration/correspondence_rejection_one_to_one.h>
+#include <pcl/registration/correspondence_rejection_sample_consensus.h>
+#include <pcl/registration/correspondence_rejection_trimmed.h>
+#include <pcl/registration/correspondence_rejection_var_trimmed.h>
+#include <pcl/registration/icp.h>
+#include <pcl/registration/transformation_estimation_svd.h>
+#include <pcl/search/kdtree.h>
+
+using namespace pcl;
+
+static int g_fail = 0, g_checks = 0;
+#define EXPECT(cond)                                                               \
+  do {                                                                             \
+    ++g_checks;                                                                    \
+    if (!(cond)) {                                                                 \
+      ++g_fail;                                                                    \
+      std::printf("  FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond);              \
+    }                                                                              \
+  } while (0)
+#define EXPECT_EQ(a, b) EXPECT((a) == (b))
+#define EXPECT_NEAR(a, b, tol) EXPECT(std::fabs(double(a) - double(b)) <= (tol))
+#define TEST(name) static void name(); static void name()
+#define RUN(name) do { int f0 = g_fail; name(); std::printf("[%s] %s\n", g_fail == f0 ? "  OK  " : "FAILED", #name); } while (0)
+
+static std::string g_dir;
+static PointCloud<PointXYZ> cloud_source, cloud_target;
+
+// ASCII .PCD v.5 reader for the fixtures (x y z floats; test/bun0.pcd:1-10)
+static bool loadPCD(const std::string &path, PointCloud<PointXYZ> &cloud) {
+  std::ifstream f(path);
+  if (!f) return false;
+  std::string line;
+  size_t n = 0;
+  while (std::getline(f, line)) {
+    if (line.compare(0, 6, "POINTS") == 0) n = std::strtoul(line.c_str() + 7, nullptr, 10);
+    if (line.compare(0, 4, "DATA") == 0) break;
+  }
+  cloud.clear();
+  for (size_t i = 0; i < n; ++i) {
+    PointXYZ p;
+    if (!(f >> p.x >> p.y >> p.z)) return false;
+    std::getline(f, line);
+    cloud.push_back(p);
+  }
+  return cloud.size() == n;
+}
+
+// the numbers of the (possibly nested) JSON array stored under "key", flattened
+static std::vector<double> jsonNumbers(const std::string &file, const std::string &key) {
+  std::ifstream f(file);
+  std::stringstream ss;
+  ss << f.rdbuf();
+  const std::string s = ss.str();
+  std::vector<double> out;
+  size_t p = s.find("\"" + key + "\"");
+  if (p == std::string::npos) return out;
+  p = s.find(':', p) + 1;
+  while (p < s.size() && std::isspace((unsigned char)s[p])) ++p;
+  if (s[p] != '[') {  // scalar
+    out.push_back(std::strtod(s.c_str() + p, nullptr));
+    return out;
+  }
+  int depth = 0;
+  for (; p < s.size(); ++p) {
+    const char c = s[p];
+    if (c == '[') ++depth;
+    else if (c == ']') { if (--depth == 0) break; }
+    else if (c == '-' || std::isdigit((unsigned char)c)) {
+      char *end;
+      out.push_back(std::strtod(s.c_str() + p, &end));
+      p = (end - s.c_str()) - 1;
+    }
+  }
+  return out;
+}
+
+// ---- test/kdtree/test_kdtree.cpp -----------------------------------------------------------------
+static PointCloud<PointXYZ> gridCloud() {  // :65-71
+  PointCloud<PointXYZ> c;
+  for (float z = -0.5f; z <= 0.5f; z += 0.1f)
+    for (float y = -0.5f; y <= 0.5f; y += 0.1f)
+      for (float x = -0.5f; x <= 0.5f; x += 0.1f) c.push_back(PointXYZ(x, y, z));
+  return c;
+}
+static float sqDist(const PointXYZ &a, const PointXYZ &b) {
+  const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+  return (dx * dx + dy * dy) + dz * dz;
+}
+
+TEST(KdTreeFLANN_radiusSearch) {  // :100-131
+  PointCloud<PointXYZ> cloud = gridCloud();
+  EXPECT_EQ(cloud.size(), size_t(1331));
+  KdTreeFLANN<PointXYZ> kdtree;
+  kdtree.setInputCloud(cloud.makeShared());
+  PointXYZ test_point(0.0f, 0.0f, 0.0f);
+  const double max_dist = 0.15;
+  std::set<int> brute;
+  for (size_t i = 0; i < cloud.size(); ++i)
+    if (sqDist(cloud[i], test_point) < float(max_dist * max_dist)) brute.insert(int(i));
+  std::vector<int> k_indices;
+  std::vector<float> k_distances;
+  kdtree.radiusSearch(test_point, max_dist, k_indices, k_distances, 100);
+  for (size_t i = 0; i < k_indices.size(); ++i) {
+    EXPECT(brute.erase(k_indices[i]) == 1);  // every result is a brute-force result
+    EXPECT(i == 0 || k_distances[i - 1] <= k_distances[i]);
+  }
+  EXPECT(brute.empty());  // and all of them were found
+  EXPECT_EQ(kdtree.radiusSearch(test_point, max_dist, k_indices, k_distances, 5), 5);
+}
+
+TEST(KdTreeFLANN_nearestKSearch) {  // :221-259
+  PointCloud<PointXYZ> cloud = gridCloud();
+  KdTreeFLANN<PointXYZ> kdtree;
+  kdtree.setInputCloud(cloud.makeShared());
+  PointXYZ test_point(0.01f, 0.01f, 0.01f);
+  const unsigned no_of_neighbors = 20;
+  std::vector<float> all;
+  for (size_t i = 0; i < cloud.size(); ++i) all.push_back(sqDist(cloud[i], test_point));
+  std::sort(all.begin(), all.end());
+  const float max_dist = all[no_of_neighbors - 1];
+  std::vector<int> k_indices(no_of_neighbors);
+  std::vector<float> k_distances(no_of_neighbors);
+  EXPECT_EQ(kdtree.nearestKSearch(test_point, no_of_neighbors, k_indices, k_distances), int(no_of_neighbors));
+  EXPECT_EQ(k_indices.size(), size_t(no_of_neighbors));
+  for (size_t i = 0; i < k_indices.size(); ++i) {
+    EXPECT(sqDist(cloud[k_indices[i]], test_point) <= max_dist);
+    EXPECT_EQ(k_distances[i], all[i]);
+  }
+  // k larger than the cloud is clamped (impl/kdtree_flann.hpp:85-86)
+  EXPECT_EQ(kdtree.nearestKSearch(test_point, 5000, k_indices, k_distances), 1331);
+  // index-based overloads (kdtree.h:204-218)
+  EXPECT_EQ(kdtree.nearestKSearch(7, 3, k_indices, k_distances), 3);
+  EXPECT_EQ(k_indices[0], 7);
+  EXPECT_EQ(k_distances[0], 0.f);
+}
+
+TEST(KdTreeFLANN_setPointRepresentation) {  // :336-398
+  const std::string kat = g_dir + "/kdtree_kat.json";
+  const std::vector<double> pts = jsonNumbers(kat, "points"), qv = jsonNumbers(kat, "query");
+  EXPECT_EQ(pts.size(), size_t(30));
+  PointCloud<PointXYZ>::Ptr random_cloud(new PointCloud<PointXYZ>);
+  for (int i = 0; i < 10; ++i) random_cloud->push_back(PointXYZ(float(pts[3 * i]), float(pts[3 * i + 1]), float(pts[3 * i + 2])));
+  KdTreeFLANN<PointXYZ> kdtree;
+  kdtree.setInputCloud(random_cloud);
+  PointXYZ p{float(qv[0]), float(qv[1]), float(qv[2])};
+  const int k = 10;
+  std::vector<int> k_indices(k);
+  std::vector<float> k_distances(k);
+  // the three cases of the fixture: default xyz, 2-D custom representation, rescaled xyz
+  const int gold_xyz[10] = {2, 7, 5, 1, 4, 6, 9, 0, 8, 3};  // test_kdtree.cpp:362
+  kdtree.nearestKSearch(p, k, k_indices, k_distances);
+  for (int i = 0; i < k; ++i) EXPECT_EQ(k_indices[i], gold_xyz[i]);
+  const std::vector<double> d0 = jsonNumbers(kat, "distances");  // first case's distances come first
+  for (int i = 0; i < k && i < int(d0.size()); ++i) EXPECT_NEAR(k_distances[i], d0[i], 0.1);
+
+  std::shared_ptr<CustomPointRepresentation<PointXYZ> > ptrep(new CustomPointRepresentation<PointXYZ>(2, 0));
+  kdtree.setPointRepresentation(ptrep);
+  kdtree.nearestKSearch(p, k, k_indices, k_distances);
+  for (int i = 0; i < k; ++i) {  // distances are 2-D now and ascending
+    const PointXYZ &c = (*random_cloud)[k_indices[i]];
+    const float dx = c.x - p.x, dy = c.y - p.y;
+    EXPECT_NEAR(k_distances[i], dx * dx + dy * dy, 1e-2);
+    EXPECT(i == 0 || k_distances[i - 1] <= k_distances[i]);
+  }
+  const int gold_xy[10] = {6, 2, 5, 1, 7, 0, 4, 3, 9, 8};  // test_kdtree.cpp:376
+  for (int i = 0; i < k; ++i) EXPECT_EQ(k_indices[i], gold_xy[i]);
+
+  DefaultPointRepresentation<PointXYZ> point_rep;
+  float alpha[3] = {1.0f, 2.0f, 3.0f};
+  point_rep.setRescaleValues(alpha);
+  kdtree.setPointRepresentation(point_rep.makeShared());
+  kdtree.nearestKSearch(p, k, k_indices, k_distances);
+  const int gold_scaled[10] = {2, 9, 4, 7, 1, 5, 8, 0, 3, 6};  // test_kdtree.cpp:390
+  for (int i = 0; i < k; ++i) EXPECT_EQ(k_indices[i], gold_scaled[i]);
+}
+
+// ---- test/search/test_kdtree.cpp:127-196 : batch == single, nearestKSearchT -----------------------
+TEST(SearchKdTree_batch_equals_single) {
+  PointCloud<PointXYZ>::Ptr cloud(new PointCloud<PointXYZ>);
+  std::srand(7);
+  for (int i = 0; i < 3000; ++i)
+    cloud->push_back(PointXYZ(float(1024 * (std::rand() / (RAND_MAX + 1.0))), float(1024 * (std::rand() / (RAND_MAX + 1.0))),
+                              float(1024 * (std::rand() / (RAND_MAX + 1.0)))));
+  search::KdTree<PointXYZ> tree;
+  tree.setInputCloud(cloud);
+  std::vector<int> query_idx;
+  for (int i = 0; i < 3000; i += 7) query_idx.push_back(i);
+  std::vector<std::vector<int> > bi;
+  std::vector<std::vector<float> > bd;
+  tree.nearestKSearch(*cloud, query_idx, 10, bi, bd);
+  EXPECT_EQ(bi.size(), query_idx.size());
+  std::vector<int> si;
+  std::vector<float> sd;
+  for (size_t i = 0; i < query_idx.size(); i += 13) {
+    tree.nearestKSearch(*cloud, query_idx[i], 10, si, sd);
+    EXPECT(si == bi[i] && sd == bd[i]);
+    EXPECT_EQ(si[0], query_idx[i]);
+  }
+  std::vector<std::vector<int> > ri;
+  std::vector<std::vector<float> > rd;
+  tree.radiusSearch(*cloud, query_idx, 60.0, ri, rd, 0);
+  for (size_t i = 0; i < query_idx.size(); i += 17) {
+    tree.radiusSearch(*cloud, query_idx[i], 60.0, si, sd, 0);
+    EXPECT(si == ri[i] && sd == rd[i]);
+    for (size_t j = 0; j < sd.size(); ++j) EXPECT(sd[j] < 3600.f && (j == 0 || sd[j - 1] <= sd[j]));
+  }
+  // a query of another point type (search.h:272-283)
+  PointXYZI qi(cloud->points[5].x, cloud->points[5].y, cloud->points[5].z, 3.f);
+  EXPECT_EQ(tree.nearestKSearchT(qi, 1, si, sd), 1);
+  EXPECT_EQ(si[0], 5);
+  // index view: results are indices of the whole cloud (impl/kdtree_flann.hpp:214-249)
+  IndicesPtr view(new std::vector<int>);
+  for (int i = 0; i < 3000; i += 3) view->push_back(i);
+  tree.setInputCloud(cloud, view);
+  tree.nearestKSearch(cloud->points[4], 5, si, sd);
+  for (size_t j = 0; j < si.size(); ++j) EXPECT(si[j] % 3 == 0);
+}
+
+// ---- test/registration/test_registration_api.cpp ---------------------------------------------------
+static bool pairsEqual(const Correspondences &c, const std::vector<double> &gold, bool check_query) {
+  if (c.size() * 2 != gold.size()) return false;
+  for (size_t i = 0; i < c.size(); ++i) {
+    if (check_query && c[i].index_query != int(gold[2 * i])) return false;
+    if (c[i].index_match != int(gold[2 * i + 1])) return false;
+  }
+  return true;
+}
+
+TEST(RegistrationAPI) {
+  const std::string api = g_dir + "/registration_api.json";
+  PointCloud<PointXYZ>::Ptr source = cloud_source.makeShared(), target = cloud_target.makeShared();
+  CorrespondencesPtr corr(new Correspondences);
+  registration::CorrespondenceEstimation<PointXYZ, PointXYZ> corr_est;
+  corr_est.setInputCloud(source);
+  corr_est.setInputTarget(target);
+  corr_est.determineCorrespondences(*corr);  // :62-79
+  EXPECT_EQ(corr->size(), size_t(397));
+  EXPECT(pairsEqual(*corr, jsonNumbers(api, "correspondences_original"), true));
+
+  Correspondences rec;
+  corr_est.determineReciprocalCorrespondences(rec);  // :82-98
+  EXPECT(pairsEqual(rec, jsonNumbers(api, "correspondences_reciprocal"), true));
+
+  Correspondences res;
+  registration::CorrespondenceRejectorDistance rej_dist;  // :101-129
+  rej_dist.setInputCorrespondences(corr);
+  rej_dist.setMaximumDistance(float(jsonNumbers(api, "rej_dist_max_dist")[0]));
+  rej_dist.getCorrespondences(res);
+  EXPECT(pairsEqual(res, jsonNumbers(api, "correspondences_dist"), true));
+  std::vector<int> rejected;
+  rej_dist.getRejectedQueryIndices(res, rejected);
+  EXPECT_EQ(rejected.size() + res.size(), corr->size());
+
+  registration::CorrespondenceRejectorOneToOne rej_oto;  // :161-181
+  rej_oto.setInputCorrespondences(corr);
+  rej_oto.getCorrespondences(res);
+  EXPECT(pairsEqual(res, jsonNumbers(api, "correspondences_one_to_one"), true));
+
+  registration::CorrespondenceRejectorTrimmed rej_trim;  // :270-295
+  rej_trim.setOverlapRadio(float(jsonNumbers(api, "rej_trimmed_overlap")[0]));
+  rej_trim.setInputCorrespondences(corr);
+  rej_trim.getCorrespondences(res);
+  EXPECT(pairsEqual(res, jsonNumbers(api, "correspondences_trimmed"), true));
+
+  registration::CorrespondenceRejectorSampleConsensus<PointXYZ> rej_sac;  // :184-216
+  rej_sac.setInputCloud(source);
+  rej_sac.setTargetCloud(target);
+  rej_sac.setInlierThreshold(jsonNumbers(api, "rej_sac_max_dist")[0]);
+  rej_sac.setMaxIterations(int(jsonNumbers(api, "rej_sac_max_iter")[0]));
+  rej_sac.setInputCorrespondences(corr);
+  rej_sac.getCorrespondences(res);
+  EXPECT(pairsEqual(res, jsonNumbers(api, "correspondences_sac"), false));  // the reference checks index_match
+  const std::vector<double> tsac = jsonNumbers(api, "transform_from_SAC");
+  Matrix4f T = rej_sac.getBestTransformation();
+  for (int i = 0; i < 16; ++i) EXPECT_NEAR(T(i / 4, i % 4), tsac[i], 1e-4);
+
+  registration::CorrespondenceRejectorMedianDistance rej_med;  // :132-158 (checked conditionally there)
+  rej_med.setInputCorrespondences(corr);
+  rej_med.setMedianFactor(0.5);
+  rej_med.getCorrespondences(res);
+  EXPECT(!res.empty() && res.size() < corr->size() && rej_med.getMedianDistance() > 0);
+  for (size_t i = 0; i < res.size(); ++i) EXPECT(res[i].distance <= rej_med.getMedianDistance() * 0.5);
+
+  registration::CorrespondenceRejectorVarTrimmed rej_var;  // :298-322
+  rej_var.setInputCorrespondences(corr);
+  rej_var.getCorrespondences(res);
+  EXPECT(res.size() < corr->size() && rej_var.getTrimFactor() >= 0.05 && rej_var.getTrimFactor() <= 0.95);
+  for (size_t i = 0; i < res.size(); ++i) EXPECT(res[i].distance < rej_var.getTrimmedDistance());
+
+  // TransformationEstimationSVD on the reciprocal pairs (:325-347)
+  registration::TransformationEstimationSVD<PointXYZ, PointXYZ> trans_est;
+  Matrix4f Tsvd;
+  trans_est.estimateRigidTransformation(*source, *target, rec, Tsvd);
+  const std::vector<double> tg = jsonNumbers(api, "transform_from_SVD");
+  for (int i = 0; i < 16; ++i) EXPECT_NEAR(Tsvd(i / 4, i % 4), tg[i], 1e-4);
+  // the index-list overloads agree with the correspondence overload
+  std::vector<int> si, ti;
+  for (size_t i = 0; i < rec.size(); ++i) { si.push_back(rec[i].index_query); ti.push_back(rec[i].index_match); }
+  Matrix4f T2;
+  trans_est.estimateRigidTransformation(*source, si, *target, ti, T2);
+  EXPECT(T2 == Tsvd);
+  PointCloud<PointXYZ> s2(*source, si), t2(*target, ti);
+  trans_est.estimateRigidTransformation(s2, t2, T2);
+  EXPECT(T2 == Tsvd);
+}
+
+// ---- test/registration/test_registration.cpp:154-188 ------------------------------------------------
+TEST(IterativeClosestPointGolden) {
+  IterativeClosestPoint<PointXYZ, PointXYZ> reg;
+  reg.setInputCloud(cloud_source.makeShared());
+  reg.setInputTarget(cloud_target.makeShared());
+  reg.setMaximumIterations(50);
+  reg.setTransformationEpsilon(1e-8);
+  reg.setMaxCorrespondenceDistance(0.05);
+  PointCloud<PointXYZ> cloud_reg;
+  reg.align(cloud_reg);
+  EXPECT_EQ(int(cloud_reg.points.size()), int(cloud_source.points.size()));
+  EXPECT(reg.hasConverged());
+  Matrix4f transformation = reg.getFinalTransformation();
+  EXPECT_NEAR(transformation(0, 0), 0.8806, 1e-3);
+  EXPECT_NEAR(transformation(0, 1), 0.036481287330389023, 1e-2);
+  EXPECT_NEAR(transformation(0, 2), -0.4724, 1e-3);
+  EXPECT_NEAR(transformation(0, 3), 0.03453, 1e-3);
+  EXPECT_NEAR(transformation(1, 0), -0.02354, 1e-3);
+  EXPECT_NEAR(transformation(1, 1), 0.9992, 1e-3);
+  EXPECT_NEAR(transformation(1, 2), 0.03326, 1e-3);
+  EXPECT_NEAR(transformation(1, 3), -0.001519, 1e-3);
+  EXPECT_NEAR(transformation(2, 0), 0.4732, 1e-3);
+  EXPECT_NEAR(transformation(2, 1), -0.01817, 1e-3);
+  EXPECT_NEAR(transformation(2, 2), 0.8808, 1e-3);
+  EXPECT_NEAR(transformation(2, 3), 0.04116, 1e-3);
+  EXPECT_EQ(transformation(3, 0), 0);
+  EXPECT_EQ(transformation(3, 1), 0);
+  EXPECT_EQ(transformation(3, 2), 0);
+  EXPECT_EQ(transformation(3, 3), 1);
+  EXPECT(reg.getFitnessScore() < 0.001);  // the bar the reference's other registration tests use (:191-320)
+  // the registered cloud is the source under the final transform
+  PointCloud<PointXYZ> moved;
+  transformPointCloud(cloud_source, moved, transformation);
+  double worst = 0;
+  for (size_t i = 0; i < moved.size(); ++i) worst = std::max(worst, double(std::sqrt(sqDist(moved[i], cloud_reg[i]))));
+  EXPECT(worst < 1e-4);
+  // a guess + an index view + too strict a threshold
+  IndicesPtr view(new std::vector<int>);
+  for (int i = 0; i < 397; i += 2) view->push_back(i);
+  reg.setIndices(view);
+  reg.align(cloud_reg, transformation);
+  EXPECT_EQ(cloud_reg.size(), view->size());
+  EXPECT(reg.hasConverged());
+  Matrix4f T2 = reg.getFinalTransformation();
+  for (int i = 0; i < 12; ++i) EXPECT_NEAR(T2(i / 4, i % 4), transformation(i / 4, i % 4), 2e-2);
+  reg.setMaxCorrespondenceDistance(1e-9);
+  reg.align(cloud_reg);
+  EXPECT(!reg.hasConverged());  // icp.hpp:103-108
+}
+
+int main(int argc, char **argv) {
+  g_dir = argc > 1 ? argv[1] : "tests/golden";
+  if (pclmi_device_count() <= 0) {
+    std::printf("no HIP device: the facade has no CPU path\n");
+    return 2;
+  }
+  if (!loadPCD(g_dir + "/bun0.pcd", cloud_source) || !loadPCD(g_dir + "/bun4.pcd", cloud_target)) {
+    std::printf("cannot read the bun fixtures under %s\n", g_dir.c_str());
+    return 2;
+  }
+  console::setVerbosityLevel(console::L_ALWAYS);  // expected-error cases print nothing
+  RUN(KdTreeFLANN_radiusSearch);
+  RUN(KdTreeFLANN_nearestKSearch);
+  RUN(KdTreeFLANN_setPointRepresentation);
+  RUN(SearchKdTree_batch_equals_single);
+  RUN(RegistrationAPI);
+  RUN(IterativeClosestPointGolden);
+  std::printf("%d checks, %d failed\n", g_checks, g_fail);
+  return g_fail ? 1 : 0;
+}
