@@ -25,6 +25,12 @@
 #include <hipcub/hipcub.hpp>
 
 #define PCLMI_STATS_OWNER
+#ifndef PCLMI_C16
+#define PCLMI_C16 32
+#endif
+#ifndef PCLMI_C32
+#define PCLMI_C32 48
+#endif
 #include "pclmi_internal.h"
 #include "traverse.hpp"
 
@@ -42,11 +48,16 @@ __device__ __forceinline__ int compact_buffer(uint2 (*buf)[64], int lane, int cn
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) maxcnt = max(maxcnt, __shfl_xor(maxcnt, o));
   int n = 0;
-  for (int e = 0; e < maxcnt; ++e) {
-    if (e < cnt) {
-      uint2 v = buf[e][lane];
-      if (__uint_as_float(v.x) <= tau) {
-        buf[n][lane] = v;
+  // four entries per step: the reads are independent and issued together, the conditional writes
+  // land at or below the read positions (n <= e), so reading ahead never sees a moved entry
+  for (int e = 0; e < maxcnt; e += 4) {
+    uint2 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = buf[min(e + u, C - 1)][lane];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (e + u < cnt && __uint_as_float(v[u].x) <= tau) {
+        buf[n][lane] = v[u];
         ++n;
       }
     }
@@ -457,9 +468,9 @@ int launch_knn(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, s
   } else if (k_eff <= 8) {
     launch_union<8, 24, 1>(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
   } else if (k_eff <= 16) {
-    launch_union<16, 32, 1>(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
+    launch_union<16, PCLMI_C16, 1>(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
   } else if (k_eff <= 32) {
-    launch_union<32, 64, 1>(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
+    launch_union<32, PCLMI_C32, 1>(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
   } else {
     size_t bytes = (size_t)k_eff * nq * sizeof(unsigned long long);
     int rc = w->ensure_scratch(bytes);

@@ -91,7 +91,8 @@ __device__ __forceinline__ void list_insert(float (&a)[K], float d) {
   // a ascending.  new a[j] = median(a[j-1], a[j], d); new a[0] = min(a[0], d).
 #pragma unroll
   for (int j = K - 1; j >= 1; --j) a[j] = __builtin_amdgcn_fmed3f(a[j - 1], a[j], d);
-  a[0] = fminf(a[0], d);
+  // min as a median with -inf: no canonicalising v_max pair around it
+  a[0] = __builtin_amdgcn_fmed3f(-__builtin_inff(), a[0], d);
 }
 
 // wave-uniform stack kept in the lanes of one VGPR

@@ -1,8 +1,12 @@
 """Quick device-resident kNN timing (development helper, not the contract bench)."""
-import sys, time
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
 import numpy as np
 import torch
 from pcl_amd import capi
+if os.environ.get('PCLMI_LIB'):
+    capi.load_library(os.environ['PCLMI_LIB'])
 
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1_000_000
 nq = int(float(sys.argv[2])) if len(sys.argv) > 2 else 1_000_000

@@ -1,6 +1,8 @@
 """Traversal statistics from the -DPCLMI_STATS build (development helper)."""
-import sys, ctypes as C
-import numpy as np, torch
+import os, sys, ctypes as C
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+import numpy as np
 from pcl_amd import capi
 capi.load_library(str(capi.LIB_PATH).replace("libpclmi.so", "libpclmi_stats.so"))
 lib = capi.load_library()
