@@ -68,11 +68,14 @@ int Workspace::ensure_queries(size_t nq, size_t nbins) {
   if (nq > cap_q) {
     size_t cap = nq + nq / 8 + 1024;
     if (keys_in) (void)hipFree(keys_in);
+    if (ranks) (void)hipFree(ranks);
     if (vals_out) (void)hipFree(vals_out);
     keys_in = nullptr;
+    ranks = nullptr;
     vals_out = nullptr;
     cap_q = 0;
     PCLMI_HIP(hipMalloc(&keys_in, cap * 4));
+    PCLMI_HIP(hipMalloc(&ranks, cap * 4));
     PCLMI_HIP(hipMalloc(&vals_out, cap * 4));
     cap_q = cap;
   }
@@ -118,6 +121,7 @@ void Workspace::release() {
   for (int i = 0; i < 4; ++i)
     if (buf[i]) (void)hipFree(buf[i]);
   if (keys_in) (void)hipFree(keys_in);
+  if (ranks) (void)hipFree(ranks);
   if (vals_out) (void)hipFree(vals_out);
   if (hist) (void)hipFree(hist);
   if (sort_tmp) (void)hipFree(sort_tmp);

@@ -372,7 +372,8 @@ __device__ __forceinline__ unsigned int spread10(unsigned int v) {
 // scatter pass replace a full radix sort.
 __global__ void cell_count_kernel(const float *__restrict__ q, int q_stride_f, int nq, float lox, float loy,
                                   float loz, float sx, float sy, float sz, int shift,
-                                  unsigned int *__restrict__ cell, unsigned int *__restrict__ hist) {
+                                  unsigned int *__restrict__ cell, unsigned int *__restrict__ rank,
+                                  unsigned int *__restrict__ hist) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nq) return;
   const float *p = q + (size_t)i * q_stride_f;
@@ -383,15 +384,14 @@ __global__ void cell_count_kernel(const float *__restrict__ q, int q_stride_f, i
   unsigned int iz = (unsigned int)fminf(fmaxf(fz, 0.f), 1023.f);
   unsigned int c = (spread10(ix) | (spread10(iy) << 1) | (spread10(iz) << 2)) >> shift;
   cell[i] = c;
-  atomicAdd(&hist[c], 1u);
+  rank[i] = atomicAdd(&hist[c], 1u);  // position inside the cell: the scatter needs no second atomic
 }
 
-__global__ void cell_scatter_kernel(const unsigned int *__restrict__ cell, int nq,
-                                    unsigned int *__restrict__ offs, int *__restrict__ order) {
+__global__ void cell_scatter_kernel(const unsigned int *__restrict__ cell, const unsigned int *__restrict__ rank,
+                                    int nq, const unsigned int *__restrict__ offs, int *__restrict__ order) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nq) return;
-  unsigned int pos = atomicAdd(&offs[cell[i]], 1u);
-  order[pos] = i;
+  order[offs[cell[i]] + rank[i]] = i;
 }
 
 }  // namespace
@@ -430,10 +430,10 @@ int launch_morton_order(const pclmi_tree *t, Workspace *w, const float *d_q, siz
   PCLMI_HIP(hipMemsetAsync(w->hist, 0, nbins * sizeof(unsigned int), s));
   const unsigned grid = (unsigned)((nq + 255) / 256);
   hipLaunchKernelGGL(cell_count_kernel, dim3(grid), dim3(256), 0, s, d_q, (int)q_stride_f, (int)nq,
-                     bb_lo[0], bb_lo[1], bb_lo[2], sc[0], sc[1], sc[2], 30 - bits, w->keys_in, w->hist);
+                     bb_lo[0], bb_lo[1], bb_lo[2], sc[0], sc[1], sc[2], 30 - bits, w->keys_in, w->ranks, w->hist);
   size_t tmp = w->cap_tmp;
   PCLMI_HIP(hipcub::DeviceScan::ExclusiveSum(w->sort_tmp, tmp, w->hist, w->hist, (int)nbins, s));
-  hipLaunchKernelGGL(cell_scatter_kernel, dim3(grid), dim3(256), 0, s, w->keys_in, (int)nq, w->hist,
+  hipLaunchKernelGGL(cell_scatter_kernel, dim3(grid), dim3(256), 0, s, w->keys_in, w->ranks, (int)nq, w->hist,
                      w->vals_out);
   PCLMI_HIP(hipGetLastError());
   *d_order = w->vals_out;

@@ -107,6 +107,7 @@ namespace pclmi {
 struct Workspace {
   // query-ordering scratch (counting sort by Morton cell)
   uint32_t *keys_in = nullptr;  // cell id per query
+  uint32_t *ranks = nullptr;    // position of the query inside its cell
   int32_t *vals_out = nullptr;  // sorted slot -> query row
   uint32_t *hist = nullptr;     // per-cell counts / running offsets
   void *sort_tmp = nullptr;     // hipcub scan temp storage
