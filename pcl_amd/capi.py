@@ -132,7 +132,8 @@ def load_library(path=None):
     if _LIB is not None:
         return _LIB
     _share_hip_runtime_with_torch()
-    p = Path(path) if path else LIB_PATH
+    import os
+    p = Path(path) if path else Path(os.environ.get("PCLMI_LIB", LIB_PATH))  # PCLMI_LIB: development override
     if not p.exists():
         raise PclmiError(2, "%s is missing - run `python -c 'import __graft_entry__ as g; g.build()'` "
                             "or `make -C pcl_amd/csrc`" % p)

@@ -25,11 +25,16 @@
 #include <hipcub/hipcub.hpp>
 
 #define PCLMI_STATS_OWNER
-#ifndef PCLMI_C16
-#define PCLMI_C16 32
+// append-buffer capacities (entries per lane) of the index-only kernels, tuned on MI355X at 1M x 1M:
+// small enough for 13-26 resident waves per CU, large enough to keep compactions rare
+#ifndef PCLMI_IX8
+#define PCLMI_IX8 24
 #endif
-#ifndef PCLMI_C32
-#define PCLMI_C32 48
+#ifndef PCLMI_IX16
+#define PCLMI_IX16 40
+#endif
+#ifndef PCLMI_IX32
+#define PCLMI_IX32 80
 #endif
 #include "pclmi_internal.h"
 #include "traverse.hpp"
@@ -111,6 +116,10 @@ __global__ __launch_bounds__(64 * WPB) void knn_union_kernel(TreeView t, const f
                                                               float *__restrict__ out_d2) {
   static_assert(C >= K + 8, "buffer must hold the K best plus two groups of appends");
   __shared__ uint2 lds[WPB][C][64];
+#ifdef PCLMI_EXTRA_LDS
+  __shared__ int pad_lds[PCLMI_EXTRA_LDS / 4];  // occupancy experiment only
+  if (nq < 0) pad_lds[threadIdx.x] = nq, out_idx[0] = pad_lds[threadIdx.x ^ 1];
+#endif
   const int lane = threadIdx.x & 63;
   LaneQuery lq;
   if (!load_lane_query<WPB>(q, q_stride_f, order, nq, lq)) return;
@@ -213,6 +222,158 @@ __global__ __launch_bounds__(64 * WPB) void knn_union_kernel(TreeView t, const f
     uint2 v = buf[j][lane];  // C >= K, always in bounds; masked by cnt
     key[j] = j < cnt ? (((unsigned long long)v.x << 32) | v.y) : ~0ull;
   }
+  sort_keys<K>(key);
+  if (lq.alive) {
+    int *oi = out_idx + (size_t)lq.qi * k_out;
+    float *od = out_d2 + (size_t)lq.qi * k_out;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      if (j < k_out) {
+        oi[j] = (int)(unsigned int)(key[j] & 0xffffffffull);
+        od[j] = __uint_as_float((unsigned int)(key[j] >> 32));
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Index-only variant: the append buffer keeps 4 bytes per entry (the external index); distances are
+// recomputed from the cloud rows (same fp32 expression, so bit-identical) when the buffer is compacted
+// and at the end.  Half the LDS per wave -> twice the resident waves; the traversal is latency-bound,
+// so occupancy is what it needs (DESIGN.md "kNN kernel").
+template <int K, int C>
+__device__ __forceinline__ int compact_index_buffer(unsigned int (*buf)[64], const float4 *__restrict__ cloud,
+                                                    float qx, float qy, float qz, int lane, int cnt, float tau,
+                                                    float (&dist_out)[K], unsigned int (&idx_out)[K], bool final) {
+  int maxcnt = cnt;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) maxcnt = max(maxcnt, __shfl_xor(maxcnt, o));
+  int n = 0;
+  // eight entries per step: index reads, then eight independent row gathers in flight together
+  for (int e = 0; e < maxcnt; e += 8) {
+    unsigned int id[8];
+    float4 p[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) id[u] = buf[min(e + u, C - 1)][lane];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) p[u] = (e + u < cnt) ? cloud[id[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float d = sq3(qx - p[u].x, qy - p[u].y, qz - p[u].z);
+      if (e + u < cnt && d <= tau) {
+        buf[n][lane] = id[u];
+        ++n;
+      }
+    }
+  }
+  if (!final && n <= K) return n;
+  // final pass (and the rare tie overflow): pull the <= C survivors' distances once more
+  // ties at the bound: drop the largest-index ties until K remain
+  while (n > K) {
+    int worst = -1;
+    unsigned int worst_idx = 0;
+    for (int e = 0; e < n; ++e) {
+      const unsigned int id = buf[e][lane];
+      const float4 p = cloud[id];
+      const float d = sq3(qx - p.x, qy - p.y, qz - p.z);
+      if (d == tau && (worst < 0 || id > worst_idx)) {
+        worst = e;
+        worst_idx = id;
+      }
+    }
+    buf[worst][lane] = buf[n - 1][lane];
+    --n;
+  }
+  if (final) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      idx_out[j] = buf[min(j, C - 1)][lane];
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const float4 p = (j < n) ? cloud[idx_out[j]] : make_float4(0.f, 0.f, 0.f, 0.f);
+      dist_out[j] = sq3(qx - p.x, qy - p.y, qz - p.z);
+    }
+  }
+  return n;
+}
+
+template <int K, int C, int WPB>
+__global__ __launch_bounds__(64 * WPB) void knn_union_ix_kernel(TreeView t, const float *__restrict__ q,
+                                                                 int q_stride_f, const int *__restrict__ order,
+                                                                 int nq, int k_out, int *__restrict__ out_idx,
+                                                                 float *__restrict__ out_d2) {
+  static_assert(C >= K + 8, "buffer must hold the K best plus two groups of appends");
+  __shared__ unsigned int lds[WPB][C][64];
+  const int lane = threadIdx.x & 63;
+  LaneQuery lq;
+  if (!load_lane_query<WPB>(q, q_stride_f, order, nq, lq)) return;
+  const float qx = lq.x, qy = lq.y, qz = lq.z;
+  unsigned int(*buf)[64] = lds[threadIdx.x >> 6];
+  const float4 *cloud = reinterpret_cast<const float4 *>(t.cloud);
+
+  const float bound = lq.searchable ? lane_bound<K>(t, qx, qy, qz) : -1.f;
+  asm volatile("" ::"v"(bound));
+  float a[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) a[j] = bound;
+  int cnt = 0;
+  float dk[K];
+  unsigned int ik[K];
+
+  LaneStack st{0, 0, lane};
+  st.push(1);
+  const cbox_ptr box = (cbox_ptr)t.box;
+  const cgrp_ptr box2 = (cgrp_ptr)t.box;
+  const cgrp_ptr leaf = (cgrp_ptr)t.leaf;
+  const int M = t.M;
+
+  while (st.sp > 0) {
+    const int node = st.pop();
+    if (node >= M) {
+      const f8v b = box[node];
+      const cgrp_ptr rec = leaf + (size_t)(node - M) * G;
+      f16v grp[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) grp[g] = rec[g];
+      const float md = box_dist(qx, qy, qz, b[0], b[1], b[2], b[3], b[4], b[5]);
+      if (!__any(md <= a[K - 1])) continue;
+      const f2v q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        float dd[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f2v d2 = sq3_pk(q2x - f2v{grp[g][2 * h], grp[g][2 * h + 1]},
+                                q2y - f2v{grp[g][4 + 2 * h], grp[g][5 + 2 * h]},
+                                q2z - f2v{grp[g][8 + 2 * h], grp[g][9 + 2 * h]});
+          dd[2 * h] = d2.x;
+          dd[2 * h + 1] = d2.y;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float d = dd[j];
+          const bool pass = d <= a[K - 1];
+          if (__any(pass)) {
+            if (pass) {
+              buf[cnt][lane] = __float_as_uint(grp[g][12 + j]);
+              ++cnt;
+            }
+            list_insert<K>(a, d);
+          }
+        }
+        if (__any(cnt > C - 4)) cnt = compact_index_buffer<K, C>(buf, cloud, qx, qy, qz, lane, cnt, a[K - 1], dk, ik, false);
+      }
+    } else {
+      expand_inner(st, box2, node, M, qx, qy, qz, a[K - 1]);
+    }
+  }
+
+  // ---- final: filter with the exact k-th distance, sort the survivors by (d2, index)
+  cnt = compact_index_buffer<K, C>(buf, cloud, qx, qy, qz, lane, cnt, a[K - 1], dk, ik, true);
+  unsigned long long key[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) key[j] = j < cnt ? (((unsigned long long)__float_as_uint(dk[j]) << 32) | ik[j]) : ~0ull;
   sort_keys<K>(key);
   if (lq.alive) {
     int *oi = out_idx + (size_t)lq.qi * k_out;
@@ -441,6 +602,16 @@ int launch_morton_order(const pclmi_tree *t, Workspace *w, const float *d_q, siz
 }
 
 template <int K, int C, int WPB>
+static void launch_union_ix(const pclmi_tree *t, const float *d_q, size_t nq, size_t qsf, const int32_t *order,
+                            int k_eff, int32_t *d_idx, float *d_d2, hipStream_t s) {
+  unsigned waves = (unsigned)((nq + 63) / 64);
+  unsigned blocks = (waves + WPB - 1) / WPB;
+  blocks = (blocks + 7) & ~7u;
+  hipLaunchKernelGGL((knn_union_ix_kernel<K, C, WPB>), dim3(blocks), dim3(64 * WPB), 0, s, t->view(), d_q,
+                     (int)qsf, order, (int)nq, k_eff, d_idx, d_d2);
+}
+
+template <int K, int C, int WPB>
 static void launch_union(const pclmi_tree *t, const float *d_q, size_t nq, size_t qsf, const int32_t *order,
                          int k_eff, int32_t *d_idx, float *d_d2, hipStream_t s) {
   unsigned waves = (unsigned)((nq + 63) / 64);
@@ -466,11 +637,11 @@ int launch_knn(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, s
   } else if (k_eff <= 4) {
     launch_union<4, 24, 4>(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
   } else if (k_eff <= 8) {
-    launch_union<8, 24, 1>(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
+    launch_union_ix<8, PCLMI_IX8, 1>(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
   } else if (k_eff <= 16) {
-    launch_union<16, PCLMI_C16, 1>(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
+    launch_union_ix<16, PCLMI_IX16, 1>(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
   } else if (k_eff <= 32) {
-    launch_union<32, PCLMI_C32, 1>(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
+    launch_union_ix<32, PCLMI_IX32, 1>(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
   } else {
     size_t bytes = (size_t)k_eff * nq * sizeof(unsigned long long);
     int rc = w->ensure_scratch(bytes);

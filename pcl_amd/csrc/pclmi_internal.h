@@ -77,6 +77,7 @@ struct TreeView {
   const float *box;  // [2M][8]  lo.xyz, hi.xyz, 0, 0   (tight bounding box of the subtree)
   const float *leaf; // [M][L/4][16]: per group of 4 points x[4], y[4], z[4], idx[4] (int bits;
                      // external row index, -1 in padded slots) - one 64-byte line per group
+  const float *cloud; // [rows][4] original rows (x, y, z, 1), addressed by the external index
   int M;             // number of leaves (>= 1 when n > 0)
   int n;             // number of indexed points
 };
@@ -99,7 +100,7 @@ struct pclmi_tree {
   mutable std::mutex mu;
   mutable std::vector<pclmi::Workspace *> pool;
 
-  pclmi::TreeView view() const { return pclmi::TreeView{d_box, d_leaf, M, (int)n}; }
+  pclmi::TreeView view() const { return pclmi::TreeView{d_box, d_leaf, d_cloud, M, (int)n}; }
 };
 
 namespace pclmi {
