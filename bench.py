@@ -195,7 +195,7 @@ def main():
                    "tree_build_s": round(build_s, 3)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "knn_union_kernel<16,...>", "kernel_ms": kern_ms, "launches": int(k_n),
+                     "kernel": "knn_union_ix_kernel<16,40,1>", "kernel_ms": kern_ms, "launches": int(k_n),
                      "algorithmic_bytes_per_launch": algo_bytes,
                      "order_ms": o_ms / max(o_n, 1)},
     }

@@ -245,8 +245,19 @@ int pclmi_tree_create(const float *xyz, size_t n, size_t stride_bytes, const int
       t->bb_lo[d] = ht.bb_lo[d];
       t->bb_hi[d] = ht.bb_hi[d];
     }
+    // AoS copy of the buckets for per-lane gathers: slot s = (x, y, z, idx bits)
+    std::vector<float> slot((size_t)ht.M * kLeafSize * 4);
+    for (size_t sl = 0; sl < (size_t)ht.M * kLeafSize; ++sl) {
+      const float *gp = &ht.leaf[(sl / kLeafSize) * 4 * kLeafSize + ((sl % kLeafSize) >> 2) * 16 + (sl & 3)];
+      slot[sl * 4 + 0] = gp[0];
+      slot[sl * 4 + 1] = gp[4];
+      slot[sl * 4 + 2] = gp[8];
+      slot[sl * 4 + 3] = gp[12];
+    }
     hipError_t e;
-    if ((e = hipMalloc(&t->d_box, ht.box.size() * 4)) != hipSuccess ||
+    if ((e = hipMalloc(&t->d_slot, slot.size() * 4)) != hipSuccess ||
+        (e = hipMemcpy(t->d_slot, slot.data(), slot.size() * 4, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMalloc(&t->d_box, ht.box.size() * 4)) != hipSuccess ||
         (e = hipMalloc(&t->d_leaf, ht.leaf.size() * 4)) != hipSuccess ||
         (e = hipMemcpy(t->d_box, ht.box.data(), ht.box.size() * 4, hipMemcpyHostToDevice)) != hipSuccess ||
         (e = hipMemcpy(t->d_leaf, ht.leaf.data(), ht.leaf.size() * 4, hipMemcpyHostToDevice)) != hipSuccess)
@@ -282,6 +293,7 @@ void pclmi_tree_destroy(pclmi_tree *t) {
   t->pool.clear();
   if (t->d_box) (void)hipFree(t->d_box);
   if (t->d_leaf) (void)hipFree(t->d_leaf);
+  if (t->d_slot) (void)hipFree(t->d_slot);
   if (t->d_cloud) (void)hipFree(t->d_cloud);
   if (t->stream) (void)hipStreamDestroy(t->stream);
   delete t;

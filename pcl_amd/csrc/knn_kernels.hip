@@ -16,15 +16,16 @@
 //   * a[K]   sorted list of the K smallest DISTANCES seen so far, kept in registers and updated
 //            with a branch-free v_med3_f32 chain: new a[j] = med3(a[j-1], a[j], d).
 //            a[K-1] is the exact running k-th distance (the pruning bound).
-//   * buf    per-lane append buffer in LDS holding (d2, index) of every candidate that was
-//            <= the bound when seen.  When a lane's buffer fills, the wave compacts it against
-//            the current bound.  At the end the buffer is filtered with the final bound and the
-//            <= K survivors are sorted by the 64-bit key (d2 bits << 32 | index) in registers.
-// This keeps the per-candidate cost at ~8 (distance) + K (med3) + ~5 (append) VALU instructions
-// and still yields the exact (d2, index) order including ties.
+//   * buf    per-lane append buffer in LDS holding the INDEX of every candidate that was <= the
+//            bound when seen (4 bytes per entry: LDS per wave decides how many waves are resident,
+//            and the traversal is latency-bound).  When a lane's buffer fills, the wave compacts it
+//            against the current bound, recomputing the distances from the cloud rows.  At the end
+//            the buffer is filtered with the final bound and the <= K survivors are sorted by the
+//            64-bit key (d2 bits << 32 | index) in registers.
+// This keeps the per-candidate cost at ~4 (packed distance) + K (med3) + ~4 (append) VALU
+// instructions and still yields the exact (d2, index) order including ties.
 #include <hipcub/hipcub.hpp>
 
-#define PCLMI_STATS_OWNER
 // append-buffer capacities (entries per lane) of the index-only kernels, tuned on MI355X at 1M x 1M:
 // small enough for 13-26 resident waves per CU, large enough to keep compactions rare
 #ifndef PCLMI_IX8
@@ -43,46 +44,6 @@ namespace pclmi {
 namespace {
 
 using namespace dev;
-
-// Compacts a lane's append buffer against bound `tau`: keeps entries with d <= tau (in place).
-// If more than K survive (distance ties at the bound) the largest-index ties are dropped until
-// exactly K remain - entries outside the current K best can never enter the final result.
-template <int K, int C>
-__device__ __forceinline__ int compact_buffer(uint2 (*buf)[64], int lane, int cnt, float tau) {
-  int maxcnt = cnt;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) maxcnt = max(maxcnt, __shfl_xor(maxcnt, o));
-  int n = 0;
-  // four entries per step: the reads are independent and issued together, the conditional writes
-  // land at or below the read positions (n <= e), so reading ahead never sees a moved entry
-  for (int e = 0; e < maxcnt; e += 4) {
-    uint2 v[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = buf[min(e + u, C - 1)][lane];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (e + u < cnt && __uint_as_float(v[u].x) <= tau) {
-        buf[n][lane] = v[u];
-        ++n;
-      }
-    }
-  }
-  // rare: ties at the bound
-  while (n > K) {
-    int worst = -1;
-    unsigned int worst_idx = 0;
-    for (int e = 0; e < n; ++e) {
-      uint2 v = buf[e][lane];
-      if (__uint_as_float(v.x) == tau && (worst < 0 || v.y > worst_idx)) {
-        worst = e;
-        worst_idx = v.y;
-      }
-    }
-    buf[worst][lane] = buf[n - 1][lane];
-    --n;
-  }
-  return n;
-}
 
 template <int N>
 __device__ __forceinline__ void sort_keys(unsigned long long (&k)[N]) {
@@ -107,140 +68,13 @@ __device__ __forceinline__ void sort_keys(unsigned long long (&k)[N]) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// K >= 2 : register distance list + LDS append buffer.  WPB waves per block, C buffer entries.
-template <int K, int C, int WPB>
-__global__ __launch_bounds__(64 * WPB) void knn_union_kernel(TreeView t, const float *__restrict__ q,
-                                                              int q_stride_f,
-                                                              const int *__restrict__ order, int nq,
-                                                              int k_out, int *__restrict__ out_idx,
-                                                              float *__restrict__ out_d2) {
-  static_assert(C >= K + 8, "buffer must hold the K best plus two groups of appends");
-  __shared__ uint2 lds[WPB][C][64];
-#ifdef PCLMI_EXTRA_LDS
-  __shared__ int pad_lds[PCLMI_EXTRA_LDS / 4];  // occupancy experiment only
-  if (nq < 0) pad_lds[threadIdx.x] = nq, out_idx[0] = pad_lds[threadIdx.x ^ 1];
-#endif
-  const int lane = threadIdx.x & 63;
-  LaneQuery lq;
-  if (!load_lane_query<WPB>(q, q_stride_f, order, nq, lq)) return;
-  const float qx = lq.x, qy = lq.y, qz = lq.z;
-  uint2(*buf)[64] = lds[threadIdx.x >> 6];
-  STAT_DECL;
-
-  // a[] = the K smallest distances seen so far, capped by the pre-pass bound: at least K points lie
-  // within `bound`, so min(bound, K-th smallest seen) is always a valid bound and ends exact.
-  STAMP(ts0);
-  const float bound = lq.searchable ? lane_bound<K>(t, qx, qy, qz) : -1.f;
-  asm volatile("" :: "v"(bound));
-  STAMP(ts1);
-  STAMP_ACC(8, ts1, ts0);
-  float a[K];
-#pragma unroll
-  for (int j = 0; j < K; ++j) a[j] = bound;
-  int cnt = 0;
-
-  LaneStack st{0, 0, lane};
-  st.push(1);
-  const cbox_ptr box = (cbox_ptr)t.box;
-  const cgrp_ptr box2 = (cgrp_ptr)t.box;
-  const cgrp_ptr leaf = (cgrp_ptr)t.leaf;
-  const int M = t.M;
-
-  while (st.sp > 0) {
-    const int node = st.pop();
-    if (node >= M) {
-      // ---- bucket: re-test its box against the (possibly tighter) bound, then scan it
-      STAMP(tb0);
-      const f8v b = box[node];
-      const cgrp_ptr rec = leaf + (size_t)(node - M) * G;
-      f16v grp[G];
-#pragma unroll
-      for (int g = 0; g < G; ++g) grp[g] = rec[g];
-#ifdef PCLMI_STATS
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-      STAMP(tb1);
-      STAMP_ACC(9, tb1, tb0);
-      const float md = box_dist(qx, qy, qz, b[0], b[1], b[2], b[3], b[4], b[5]);
-      STAT_ADD(1, 1);
-      if (!__any(md <= a[K - 1])) continue;
-      STAT_ADD(2, 1);
-      const f2v q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        float dd[4];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const f2v d2 = sq3_pk(q2x - f2v{grp[g][2 * h], grp[g][2 * h + 1]},
-                                q2y - f2v{grp[g][4 + 2 * h], grp[g][5 + 2 * h]},
-                                q2z - f2v{grp[g][8 + 2 * h], grp[g][9 + 2 * h]});
-          dd[2 * h] = d2.x;
-          dd[2 * h + 1] = d2.y;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float d = dd[j];
-          const bool pass = d <= a[K - 1];
-          if (__any(pass)) {  // wave-uniform: the insert is a no-op for lanes that do not pass
-            STAT_ADD(3, 1);
-            STAT_ADD(4, __builtin_amdgcn_readfirstlane(pass ? 1 : 0));
-            if (pass) {
-              buf[cnt][lane] = make_uint2(__float_as_uint(d), __float_as_uint(grp[g][12 + j]));
-              ++cnt;
-            }
-            list_insert<K>(a, d);
-          }
-        }
-        // keep room for the next group of 4 appends
-        if (__any(cnt > C - 4)) {
-          STAT_ADD(5, 1);
-          STAMP(tc0);
-          cnt = compact_buffer<K, C>(buf, lane, cnt, a[K - 1]);
-          STAMP(tc1);
-          STAMP_ACC(10, tc1, tc0);
-        }
-      }
-      STAMP(tb2);
-      STAMP_ACC(11, tb2, tb1);
-    } else {
-      STAT_ADD(0, 1);
-      STAMP(ti0);
-      expand_inner(st, box2, node, M, qx, qy, qz, a[K - 1]);
-      STAMP(ti1);
-      STAMP_ACC(12, ti1, ti0);
-    }
-  }
-  STAMP(tf0);
-  STAMP_ACC(13, tf0, ts0);
-  STAT_FLUSH;
-
-  // ---- final: filter with the exact k-th distance, sort the survivors by (d2, index)
-  cnt = compact_buffer<K, C>(buf, lane, cnt, a[K - 1]);
-  unsigned long long key[K];
-#pragma unroll
-  for (int j = 0; j < K; ++j) {
-    uint2 v = buf[j][lane];  // C >= K, always in bounds; masked by cnt
-    key[j] = j < cnt ? (((unsigned long long)v.x << 32) | v.y) : ~0ull;
-  }
-  sort_keys<K>(key);
-  if (lq.alive) {
-    int *oi = out_idx + (size_t)lq.qi * k_out;
-    float *od = out_d2 + (size_t)lq.qi * k_out;
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-      if (j < k_out) {
-        oi[j] = (int)(unsigned int)(key[j] & 0xffffffffull);
-        od[j] = __uint_as_float((unsigned int)(key[j] >> 32));
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Index-only variant: the append buffer keeps 4 bytes per entry (the external index); distances are
-// recomputed from the cloud rows (same fp32 expression, so bit-identical) when the buffer is compacted
-// and at the end.  Half the LDS per wave -> twice the resident waves; the traversal is latency-bound,
-// so occupancy is what it needs (DESIGN.md "kNN kernel").
+// K >= 2.  The append buffer keeps 4 bytes per entry (the bucket slot of the point); distances are
+// recomputed from the slot rows (x, y, z, idx) (same fp32 expression, so bit-identical) when the buffer is compacted and at the
+// end.  Half the LDS per wave of a (d2, index) buffer -> twice the resident waves; the traversal is
+// latency-bound, so occupancy is what it needs (DESIGN.md "kNN kernel").
+// Compaction keeps entries with d <= tau (in place); if more than K survive (distance ties at the bound)
+// the largest-index ties are dropped until exactly K remain - entries outside the current K best can
+// never enter the final result.
 template <int K, int C>
 __device__ __forceinline__ int compact_index_buffer(unsigned int (*buf)[64], const float4 *__restrict__ cloud,
                                                     float qx, float qy, float qz, int lane, int cnt, float tau,
@@ -273,8 +107,8 @@ __device__ __forceinline__ int compact_index_buffer(unsigned int (*buf)[64], con
     int worst = -1;
     unsigned int worst_idx = 0;
     for (int e = 0; e < n; ++e) {
-      const unsigned int id = buf[e][lane];
-      const float4 p = cloud[id];
+      const float4 p = cloud[buf[e][lane]];
+      const unsigned int id = __float_as_uint(p.w);  // external index
       const float d = sq3(qx - p.x, qy - p.y, qz - p.z);
       if (d == tau && (worst < 0 || id > worst_idx)) {
         worst = e;
@@ -285,14 +119,14 @@ __device__ __forceinline__ int compact_index_buffer(unsigned int (*buf)[64], con
     --n;
   }
   if (final) {
+    unsigned int sl[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) sl[j] = buf[min(j, C - 1)][lane];
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-      idx_out[j] = buf[min(j, C - 1)][lane];
-    }
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-      const float4 p = (j < n) ? cloud[idx_out[j]] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 p = (j < n) ? cloud[sl[j]] : make_float4(0.f, 0.f, 0.f, 0.f);
       dist_out[j] = sq3(qx - p.x, qy - p.y, qz - p.z);
+      idx_out[j] = __float_as_uint(p.w);
     }
   }
   return n;
@@ -310,7 +144,7 @@ __global__ __launch_bounds__(64 * WPB) void knn_union_ix_kernel(TreeView t, cons
   if (!load_lane_query<WPB>(q, q_stride_f, order, nq, lq)) return;
   const float qx = lq.x, qy = lq.y, qz = lq.z;
   unsigned int(*buf)[64] = lds[threadIdx.x >> 6];
-  const float4 *cloud = reinterpret_cast<const float4 *>(t.cloud);
+  const float4 *cloud = reinterpret_cast<const float4 *>(t.slot);  // bucket-slot rows (x, y, z, idx bits)
 
   const float bound = lq.searchable ? lane_bound<K>(t, qx, qy, qz) : -1.f;
   asm volatile("" ::"v"(bound));
@@ -356,7 +190,7 @@ __global__ __launch_bounds__(64 * WPB) void knn_union_ix_kernel(TreeView t, cons
           const bool pass = d <= a[K - 1];
           if (__any(pass)) {
             if (pass) {
-              buf[cnt][lane] = __float_as_uint(grp[g][12 + j]);
+              buf[cnt][lane] = (unsigned int)(node - M) * L + g * 4 + j;  // bucket slot
               ++cnt;
             }
             list_insert<K>(a, d);
@@ -557,15 +391,6 @@ __global__ void cell_scatter_kernel(const unsigned int *__restrict__ cell, const
 
 }  // namespace
 
-#ifdef PCLMI_STATS
-extern "C" void pclmi_debug_stats(unsigned long long *out, int reset) {
-  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(dev::g_stats), sizeof(unsigned long long) * 16);
-  if (reset) {
-    unsigned long long z[16] = {0};
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(dev::g_stats), z, sizeof(z));
-  }
-}
-#endif
 
 int launch_morton_order(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq,
                         size_t q_stride_f, const float *bb_lo, const float *bb_hi, hipStream_t s,
@@ -611,16 +436,6 @@ static void launch_union_ix(const pclmi_tree *t, const float *d_q, size_t nq, si
                      (int)qsf, order, (int)nq, k_eff, d_idx, d_d2);
 }
 
-template <int K, int C, int WPB>
-static void launch_union(const pclmi_tree *t, const float *d_q, size_t nq, size_t qsf, const int32_t *order,
-                         int k_eff, int32_t *d_idx, float *d_d2, hipStream_t s) {
-  unsigned waves = (unsigned)((nq + 63) / 64);
-  unsigned blocks = (waves + WPB - 1) / WPB;
-  blocks = (blocks + 7) & ~7u;  // the XCD remap assumes a multiple of 8
-  hipLaunchKernelGGL((knn_union_kernel<K, C, WPB>), dim3(blocks), dim3(64 * WPB), 0, s, t->view(), d_q,
-                     (int)qsf, order, (int)nq, k_eff, d_idx, d_d2);
-}
-
 int launch_knn(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, size_t qsf,
                const int32_t *order, int k_eff, int32_t *d_idx, float *d_d2, hipStream_t s) {
   if (nq == 0 || k_eff <= 0) return PCLMI_OK;
@@ -633,9 +448,9 @@ int launch_knn(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, s
     hipLaunchKernelGGL((knn1_union_kernel<WPB>), dim3(blocks), dim3(64 * WPB), 0, s, t->view(), d_q, (int)qsf,
                        order, (int)nq, d_idx, d_d2);
   } else if (k_eff <= 2) {
-    launch_union<2, 24, 4>(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
+    launch_union_ix<2, 16, 1>(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
   } else if (k_eff <= 4) {
-    launch_union<4, 24, 4>(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
+    launch_union_ix<4, 16, 1>(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
   } else if (k_eff <= 8) {
     launch_union_ix<8, PCLMI_IX8, 1>(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
   } else if (k_eff <= 16) {

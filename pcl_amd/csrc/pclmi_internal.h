@@ -78,6 +78,9 @@ struct TreeView {
   const float *leaf; // [M][L/4][16]: per group of 4 points x[4], y[4], z[4], idx[4] (int bits;
                      // external row index, -1 in padded slots) - one 64-byte line per group
   const float *cloud; // [rows][4] original rows (x, y, z, 1), addressed by the external index
+  const float *slot;  // [M * L][4] the bucket points again as (x, y, z, idx bits), addressed by
+                      // bucket slot = leaf number * L + position: the per-lane gathers of the kNN
+                      // buffer compaction stay inside the part of the tree the XCD already holds in L2
   int M;             // number of leaves (>= 1 when n > 0)
   int n;             // number of indexed points
 };
@@ -93,6 +96,7 @@ struct pclmi_tree {
   int M = 0;             // leaves
   float *d_box = nullptr;
   float *d_leaf = nullptr;
+  float *d_slot = nullptr;   // [M * L][4] (x, y, z, idx bits) in bucket order
   float *d_cloud = nullptr;  // [rows][4] copy of the original cloud (x, y, z, 1) for ICP gathers
   float bb_lo[3] = {0, 0, 0}, bb_hi[3] = {0, 0, 0};
   hipStream_t stream = nullptr;
@@ -100,7 +104,7 @@ struct pclmi_tree {
   mutable std::mutex mu;
   mutable std::vector<pclmi::Workspace *> pool;
 
-  pclmi::TreeView view() const { return pclmi::TreeView{d_box, d_leaf, d_cloud, M, (int)n}; }
+  pclmi::TreeView view() const { return pclmi::TreeView{d_box, d_leaf, d_cloud, d_slot, M, (int)n}; }
 };
 
 namespace pclmi {

@@ -18,27 +18,7 @@ typedef const f16v __attribute__((address_space(4))) *cgrp_ptr;   // 64-byte lin
 constexpr int L = kLeafSize;
 constexpr int G = L / 4;
 
-#ifdef PCLMI_STATS
-// development statistics (never compiled into the shipped library)
-#ifdef PCLMI_STATS_OWNER
-__device__ unsigned long long g_stats[16];
-#else
-extern __device__ unsigned long long g_stats[16];
-#endif
-#define STAT_DECL unsigned long long sacc_[16] = {0}
-#define STAT_ADD(i, v) do { sacc_[i] += (unsigned long long)(v); } while (0)
-#define STAT_FLUSH do { if (lane == 0) { _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&g_stats[i_], sacc_[i_]); } } while (0)
-// cycle stamps: one statement = s_memtime + its wait, fenced for the scheduler (diagnostic build only)
-#define STAMP(var) unsigned long long var; __builtin_amdgcn_sched_barrier(0); \
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0)
-#define STAMP_ACC(i, t1, t0) STAT_ADD(i, (t1) - (t0))
-#else
-#define STAT_DECL do { } while (0)
-#define STAT_FLUSH do { } while (0)
-#define STAT_ADD(i, v) do { } while (0)
-#define STAMP(var) do { } while (0)
-#define STAMP_ACC(i, t1, t0) do { } while (0)
-#endif  // point groups per bucket: [x0..3 | y0..3 | z0..3 | idx0..3]
+// point groups per bucket: [x0..3 | y0..3 | z0..3 | idx0..3]
 
 __device__ __forceinline__ float sq3(float dx, float dy, float dz) {
   // one rounding per operation, fixed order: ((dx*dx + dy*dy) + dz*dz)

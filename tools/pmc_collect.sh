@@ -11,4 +11,4 @@ run() {
 }
 run fetch FETCH_SIZE && run write WRITE_SIZE && run tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum && \
 run sq SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD && \
-python3 tools/pmc_summary.py gpurun_out knn_union_kernel gpurun_out/pmc_summary_k$K.json
+python3 tools/pmc_summary.py gpurun_out knn_union gpurun_out/pmc_summary_k$K.json
