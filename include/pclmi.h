@@ -111,8 +111,9 @@ int pclmi_radius(const pclmi_tree *t, const float *queries, size_t nq, size_t q_
                  double radius, uint32_t max_nn, int sorted, uint64_t *offsets, int32_t **idx,
                  float **d2);
 /* Device-resident variant: d_offsets has nq + 1 entries; *d_idx / *d_d2 are DEVICE
- * buffers allocated by the library (release with pclmi_free_dev); *total receives
- * offsets[nq].  Synchronises `stream` (the output size is data dependent). */
+ * buffers allocated by the library (release with pclmi_free_dev once no queued work still
+ * reads them: released buffers are recycled by later searches, not handed back to HIP);
+ * *total receives offsets[nq].  Synchronises `stream` (the output size is data dependent). */
 int pclmi_radius_dev(const pclmi_tree *t, const float *d_queries, size_t nq, size_t q_stride_bytes,
                      double radius, uint32_t max_nn, int sorted, uint64_t *d_offsets,
                      int32_t **d_idx, float **d_d2, uint64_t *total, void *stream);

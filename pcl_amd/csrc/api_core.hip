@@ -64,6 +64,90 @@ TimingScope::~TimingScope() {
   g_pending.push_back(r);
 }
 
+// ---- result-buffer cache ------------------------------------------------------------------------
+// hipMalloc / hipFree cost ~0.1 ms each and hipFree synchronises the device; the variable-length
+// results of pclmi_radius_dev are therefore recycled: pclmi_free_dev parks up to kCacheSlots buffers
+// per process, the next search takes the smallest parked buffer that fits.
+namespace {
+struct CacheEntry {
+  void *p;
+  size_t bytes;
+  int device;
+};
+constexpr int kCacheSlots = 8;
+constexpr size_t kCacheMaxBytes = (size_t)4 << 30;
+std::mutex g_cmu;
+std::vector<CacheEntry> g_parked;   // free buffers
+std::vector<CacheEntry> g_handed;   // buffers currently owned by callers (size lookup for put)
+}  // namespace
+
+void *dev_cache_get(size_t bytes) {
+  if (bytes == 0) bytes = 4;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  {
+    std::lock_guard<std::mutex> g(g_cmu);
+    int best = -1;
+    for (int i = 0; i < (int)g_parked.size(); ++i)
+      if (g_parked[i].device == dev && g_parked[i].bytes >= bytes && g_parked[i].bytes <= 2 * bytes + 4096 &&
+          (best < 0 || g_parked[i].bytes < g_parked[best].bytes))
+        best = i;
+    if (best >= 0) {
+      CacheEntry e = g_parked[best];
+      g_parked.erase(g_parked.begin() + best);
+      g_handed.push_back(e);
+      return e.p;
+    }
+  }
+  void *p = nullptr;
+  const size_t cap = bytes + bytes / 16;  // a little slack so that similar-sized results reuse it
+  hipError_t e = hipMalloc(&p, cap);
+  if (e != hipSuccess) {
+    // make room and retry once
+    std::vector<CacheEntry> drop;
+    {
+      std::lock_guard<std::mutex> g(g_cmu);
+      drop.swap(g_parked);
+    }
+    for (auto &d : drop) (void)hipFree(d.p);
+    e = hipMalloc(&p, cap);
+    if (e != hipSuccess) {
+      (void)hip_fail(e, "result buffer allocation", __FILE__, __LINE__);
+      return nullptr;
+    }
+  }
+  std::lock_guard<std::mutex> g(g_cmu);
+  g_handed.push_back(CacheEntry{p, cap, dev});
+  return p;
+}
+
+void dev_cache_put(void *p) {
+  if (!p) return;
+  CacheEntry e{p, 0, 0};
+  bool known = false;
+  void *evict = nullptr;
+  {
+    std::lock_guard<std::mutex> g(g_cmu);
+    for (size_t i = 0; i < g_handed.size(); ++i)
+      if (g_handed[i].p == p) {
+        e = g_handed[i];
+        g_handed.erase(g_handed.begin() + i);
+        known = true;
+        break;
+      }
+    if (known && e.bytes <= kCacheMaxBytes) {
+      if ((int)g_parked.size() >= kCacheSlots) {  // evict the oldest
+        evict = g_parked.front().p;
+        g_parked.erase(g_parked.begin());
+      }
+      g_parked.push_back(e);
+      p = nullptr;
+    }
+  }
+  if (evict) (void)hipFree(evict);
+  if (p) (void)hipFree(p);  // not ours to cache (or too large)
+}
+
 int Workspace::ensure_queries(size_t nq, size_t nbins) {
   if (nq > cap_q) {
     size_t cap = nq + nq / 8 + 1024;
@@ -359,8 +443,6 @@ int pclmi_knn(const pclmi_tree *t, const float *q, size_t nq, size_t q_stride_by
 }
 
 void pclmi_free(void *p) { free(p); }
-void pclmi_free_dev(void *p) {
-  if (p) (void)hipFree(p);
-}
+void pclmi_free_dev(void *p) { dev_cache_put(p); }
 
 }  // extern "C"

@@ -158,6 +158,10 @@ int launch_knn(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, s
                const int32_t *d_order, int k_eff, int32_t *d_idx, float *d_d2, hipStream_t s);
 
 
+// ---- small cache of result buffers (api_core.hip): pclmi_free_dev parks, radius search reuses ----
+void *dev_cache_get(size_t bytes);  // nullptr on allocation failure (error text set)
+void dev_cache_put(void *p);       // nullptr is ignored
+
 // ---- radius search (radius_kernels.hip) ---------------------------------------------------
 // Whole device-side pipeline of pclmi_radius_dev; *d_idx / *d_d2 are hipMalloc'd here.
 int radius_search_dev(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, size_t q_stride_f,

@@ -10,7 +10,8 @@
 //   3. fill pass    - the same traversal again, every lane appending 64-bit keys
 //                     (d2 bits << 32 | index, or index << 32 | d2 bits for unsorted output) to its
 //                     own segment;
-//   4. per-segment sort of the keys (an in-LDS bitonic network per segment up to 1024 entries,
+//   4. per-segment sort of the keys (up to 64 entries: one wave, one key per lane, bitonic network
+//                     through cross-lane shuffles; up to 1024: bitonic network in LDS;
 //                     hipcub::DeviceSegmentedSort for the rare longer ones);
 //   5. split of the keys into the idx / d2 arrays (and truncation to max_nn).
 // Queries are visited in Morton-cell order like the kNN path; segments are laid out in the caller's
@@ -107,11 +108,7 @@ __global__ __launch_bounds__(64) void segment_sort_kernel(u64 *__restrict__ keys
   const int seg = blockIdx.x;
   const u64 a = offsets[seg], b = offsets[seg + 1];
   const u64 len64 = b - a;
-  if (len64 < 2) return;  // block-uniform
-  if (len64 > (u64)SEG_MAX) {
-    if (lane == 0) atomicAdd(n_long, 1u);
-    return;
-  }
+  if (len64 <= 64 || len64 > (u64)SEG_MAX) return;  // block-uniform: short ones are done, long ones go to hipcub
   const int len = (int)len64;
   int P = 64;
   while (P < len) P <<= 1;
@@ -134,6 +131,71 @@ __global__ __launch_bounds__(64) void segment_sort_kernel(u64 *__restrict__ keys
     }
   }
   for (int i = lane; i < len; i += 64) keys[a + i] = s[i];
+}
+
+// Segments of up to 64 keys (the common case: ~32 neighbours per query): one wave per segment, one key
+// per lane, bitonic network through cross-lane shuffles - no LDS, no barriers.  Counts the segments it
+// leaves to the other two paths: counters[0] = longer than 64, counters[1] = longer than SEG_MAX.
+constexpr int SORT64_WPB = 4;
+__global__ __launch_bounds__(64 * SORT64_WPB) void segment_sort64_kernel(u64 *__restrict__ keys,
+                                                                          const u64 *__restrict__ offsets, int nq,
+                                                                          unsigned int *__restrict__ counters,
+                                                                          int by_index, int *__restrict__ idx_out,
+                                                                          float *__restrict__ d2_out) {
+  // idx_out != null: the sorted keys of the segments handled here go straight to the idx / d2 arrays
+  // (same offsets); the longer segments are split by split_long_kernel after their own sort
+  const int lane = threadIdx.x & 63;
+  const int seg = blockIdx.x * SORT64_WPB + (threadIdx.x >> 6);
+  if (seg >= nq) return;
+  const u64 a = offsets[seg], b = offsets[seg + 1];
+  const u64 len64 = b - a;
+  if (len64 == 0) return;
+  if (len64 > 64) {
+    if (lane == 0) {
+      atomicAdd(&counters[0], 1u);
+      if (len64 > (u64)SEG_MAX) atomicAdd(&counters[1], 1u);
+    }
+    return;
+  }
+  const int len = (int)len64;
+  u64 key = lane < len ? keys[a + lane] : ~0ull;
+  int P = 2;
+  while (P < len) P <<= 1;  // wave-uniform: stages beyond the padded length are skipped
+  for (int size = 2; size <= P; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      const u64 other = __shfl_xor(key, stride);
+      const bool up = (lane & size) == 0;
+      const bool lower = (lane & stride) == 0;
+      const u64 mn = key < other ? key : other, mx = key < other ? other : key;
+      key = (lower == up) ? mn : mx;
+    }
+  }
+  if (lane < len) {
+    if (idx_out) {
+      const unsigned int hi = (unsigned int)(key >> 32), lo = (unsigned int)key;
+      idx_out[a + lane] = (int)(by_index ? hi : lo);
+      d2_out[a + lane] = __uint_as_float(by_index ? lo : hi);
+    } else {
+      keys[a + lane] = key;
+    }
+  }
+}
+
+// keys -> idx / d2 for the segments longer than 64 entries (one wave per segment)
+__global__ __launch_bounds__(256) void split_long_kernel(const u64 *__restrict__ keys, const u64 *__restrict__ offsets,
+                                                         int nq, int by_index, int *__restrict__ idx,
+                                                         float *__restrict__ d2) {
+  const int lane = threadIdx.x & 63;
+  const int seg = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (seg >= nq) return;
+  const u64 a = offsets[seg], b = offsets[seg + 1];
+  if (b - a <= 64) return;
+  for (u64 i = a + lane; i < b; i += 64) {
+    const u64 k = keys[i];
+    const unsigned int hi = (unsigned int)(k >> 32), lo = (unsigned int)k;
+    idx[i] = (int)(by_index ? hi : lo);
+    d2[i] = __uint_as_float(by_index ? lo : hi);
+  }
 }
 
 // offsets for hipcub: segments handled by segment_sort_kernel are presented as empty
@@ -203,16 +265,30 @@ int scan_counts(Workspace *w, const unsigned int *d_counts, size_t nq, u64 *d_of
 
 // sorts every CSR segment of `keys` ascending; `alt` is a second buffer of the same size (hipcub
 // path only).  On return *sorted_in receives the buffer holding the result.
+// idx_out / d2_out non-null: additionally split the sorted keys into those arrays (same offsets).
 int sort_segments(Workspace *w, u64 *keys, u64 *alt, const u64 *d_offsets, size_t nq, u64 total,
-                  unsigned int *d_nlong, u64 **sorted_in, hipStream_t s) {
+                  unsigned int *d_nlong, u64 **sorted_in, hipStream_t s, int by_index = 0, int *idx_out = nullptr,
+                  float *d2_out = nullptr) {
   *sorted_in = keys;
-  if (total < 2) return PCLMI_OK;
-  PCLMI_HIP(hipMemsetAsync(d_nlong, 0, sizeof(unsigned int), s));
-  hipLaunchKernelGGL(segment_sort_kernel, dim3((unsigned)nq), dim3(64), 0, s, keys, d_offsets, (int)nq, d_nlong);
-  unsigned int n_long = 0;
-  PCLMI_HIP(hipMemcpyAsync(&n_long, d_nlong, sizeof(n_long), hipMemcpyDeviceToHost, s));
+  if (total == 0) return PCLMI_OK;
+  PCLMI_HIP(hipMemsetAsync(d_nlong, 0, 2 * sizeof(unsigned int), s));
+  hipLaunchKernelGGL(segment_sort64_kernel, dim3((unsigned)((nq + SORT64_WPB - 1) / SORT64_WPB)),
+                     dim3(64 * SORT64_WPB), 0, s, keys, d_offsets, (int)nq, d_nlong, by_index, idx_out, d2_out);
+  unsigned int cnts[2] = {0, 0};  // segments longer than 64 / longer than SEG_MAX
+  PCLMI_HIP(hipMemcpyAsync(cnts, d_nlong, sizeof(cnts), hipMemcpyDeviceToHost, s));
   PCLMI_HIP(hipStreamSynchronize(s));
-  if (n_long == 0) return PCLMI_OK;
+  if (cnts[0] > cnts[1])
+    hipLaunchKernelGGL(segment_sort_kernel, dim3((unsigned)nq), dim3(64), 0, s, keys, d_offsets, (int)nq, d_nlong);
+  const unsigned int n_long = cnts[1];
+  auto split_long = [&]() {
+    if (idx_out && cnts[0] > 0)
+      hipLaunchKernelGGL(split_long_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, (const u64 *)keys,
+                         d_offsets, (int)nq, by_index, idx_out, d2_out);
+  };
+  if (n_long == 0) {
+    split_long();
+    return PCLMI_OK;
+  }
   // rare: some segments exceed the LDS network; sort those with hipcub, in place via a copy
   PCLMI_CHECK(total < ((u64)1 << 31), PCLMI_ERR_UNSUPPORTED,
               "radius search: a segment longer than %d entries in a batch of more than 2^31-1 results", SEG_MAX);
@@ -232,6 +308,7 @@ int sort_segments(Workspace *w, u64 *keys, u64 *alt, const u64 *d_offsets, size_
   // already sorted keys that are in `keys`.
   PCLMI_HIP(hipcub::DeviceSegmentedSort::SortKeys(w->buf[3], need, (const u64 *)alt, keys, (int)total, (int)nq, beg,
                                                   end, s));
+  split_long();
   return PCLMI_OK;
 }
 
@@ -253,8 +330,8 @@ int radius_search_dev(const pclmi_tree *t, Workspace *w, const float *d_q, size_
   const int32_t *order = nullptr;
   int rc = launch_morton_order(t, w, d_q, nq, qsf, nullptr, nullptr, s, &order);
   if (rc) return rc;
-  // buf[0]: counts[nq + 1] (u32) | n_long (u32) | full offsets[nq + 1] (u64, only with max_nn)
-  const size_t counts_bytes = ((nq + 2) * sizeof(unsigned int) + 15) & ~(size_t)15;
+  // buf[0]: counts[nq + 1] (u32) | segment-length counters[2] (u32) | full offsets[nq + 1] (u64, only with max_nn)
+  const size_t counts_bytes = ((nq + 3) * sizeof(unsigned int) + 15) & ~(size_t)15;
   rc = w->ensure_buf(0, counts_bytes + (nq + 1) * sizeof(u64));
   if (rc) return rc;
   unsigned int *d_counts = (unsigned int *)w->buf[0];
@@ -289,52 +366,52 @@ int radius_search_dev(const pclmi_tree *t, Workspace *w, const float *d_q, size_
     hipLaunchKernelGGL((radius_union_kernel<true>), dim3(blocks), dim3(64 * R_WPB), 0, s, t->view(), d_q, (int)qsf,
                        order, (int)nq, r2, tau_r, by_index, (unsigned int *)nullptr, (const u64 *)d_off_full, keys);
   }
+  int32_t *oi = nullptr;
+  float *od = nullptr;
+  auto fail = [&](int code) {
+    dev_cache_put(oi);
+    dev_cache_put(od);
+    return code;
+  };
+  auto alloc_out = [&](u64 count) -> int {
+    oi = (int32_t *)dev_cache_get(count * sizeof(int32_t));
+    od = (float *)dev_cache_get(count * sizeof(float));
+    if (!oi || !od) return fail(PCLMI_ERR_OOM);
+    return PCLMI_OK;
+  };
   u64 *res = nullptr;
-  rc = sort_segments(w, keys, alt, d_off_full, nq, total, d_nlong, &res, s);
-  if (rc) return rc;
-
   u64 out_total = total;
-  if (max_nn) {
+  hipError_t e;
+  if (!max_nn) {
+    // outputs share the CSR offsets of the keys: the sort kernels write idx / d2 directly
+    if ((rc = alloc_out(total))) return rc;
+    rc = sort_segments(w, keys, alt, d_off_full, nq, total, d_nlong, &res, s, by_index, oi, od);
+    if (rc) return fail(rc);
+  } else {
+    rc = sort_segments(w, keys, alt, d_off_full, nq, total, d_nlong, &res, s);
+    if (rc) return rc;
     hipLaunchKernelGGL(clamp_counts_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, d_counts, (int)nq,
                        (unsigned int)max_nn);
     rc = scan_counts(w, d_counts, nq, (u64 *)d_offsets, s);
     if (rc) return rc;
     PCLMI_HIP(hipMemcpyAsync(&out_total, d_offsets + nq, sizeof(u64), hipMemcpyDeviceToHost, s));
     PCLMI_HIP(hipStreamSynchronize(s));
-  }
-  int32_t *oi = nullptr;
-  float *od = nullptr;
-  hipError_t e;
-  if ((e = hipMalloc(&oi, out_total * sizeof(int32_t))) != hipSuccess ||
-      (e = hipMalloc(&od, out_total * sizeof(float))) != hipSuccess) {
-    if (oi) (void)hipFree(oi);
-    return hip_fail(e, "radius result allocation", __FILE__, __LINE__);
-  }
-  auto fail = [&](int code) {
-    (void)hipFree(oi);
-    (void)hipFree(od);
-    return code;
-  };
-  const unsigned seg_blocks = (unsigned)((nq + 3) / 4);
-  if (!max_nn) {
-    hipLaunchKernelGGL(split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const u64 *)res, total,
-                       by_index, oi, od);
-  } else if (sorted) {
-    hipLaunchKernelGGL(truncate_kernel, dim3(seg_blocks), dim3(256), 0, s, (const u64 *)res,
-                       (const u64 *)d_off_full, (const u64 *)d_offsets, (int)nq, oi, od, (u64 *)nullptr);
-  } else {
-    // nearest max_nn, then ascending index: truncate into index-major keys, sort again, split
-    u64 *other = (res == keys) ? alt : keys;
-    hipLaunchKernelGGL(truncate_kernel, dim3(seg_blocks), dim3(256), 0, s, (const u64 *)res,
-                       (const u64 *)d_off_full, (const u64 *)d_offsets, (int)nq, (int *)nullptr, (float *)nullptr,
-                       other);
-    // max_nn <= SEG_MAX keeps every truncated segment inside the LDS network; beyond that the
-    // hipcub path needs a free second buffer: reuse the source buffer (its content is dead now)
-    u64 *res2 = nullptr;
-    rc = sort_segments(w, other, res, (const u64 *)d_offsets, nq, out_total, d_nlong, &res2, s);
-    if (rc) return fail(rc);
-    hipLaunchKernelGGL(split_kernel, dim3((unsigned)((out_total + 255) / 256)), dim3(256), 0, s, (const u64 *)res2,
-                       out_total, 1, oi, od);
+    if ((rc = alloc_out(out_total))) return rc;
+    const unsigned seg_blocks = (unsigned)((nq + 3) / 4);
+    if (sorted) {
+      hipLaunchKernelGGL(truncate_kernel, dim3(seg_blocks), dim3(256), 0, s, (const u64 *)res,
+                         (const u64 *)d_off_full, (const u64 *)d_offsets, (int)nq, oi, od, (u64 *)nullptr);
+    } else {
+      // nearest max_nn, then ascending index: truncate into index-major keys, sort again (splitting)
+      u64 *other = (res == keys) ? alt : keys;
+      hipLaunchKernelGGL(truncate_kernel, dim3(seg_blocks), dim3(256), 0, s, (const u64 *)res,
+                         (const u64 *)d_off_full, (const u64 *)d_offsets, (int)nq, (int *)nullptr, (float *)nullptr,
+                         other);
+      // the source buffer's content is dead now: it serves as the spare buffer of the hipcub path
+      u64 *res2 = nullptr;
+      rc = sort_segments(w, other, res, (const u64 *)d_offsets, nq, out_total, d_nlong, &res2, s, 1, oi, od);
+      if (rc) return fail(rc);
+    }
   }
   if ((e = hipGetLastError()) != hipSuccess || (e = hipStreamSynchronize(s)) != hipSuccess)
     return fail(hip_fail(e, "radius search", __FILE__, __LINE__));
