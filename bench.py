@@ -19,7 +19,9 @@ The same line carries
   cpu_baseline  the CPU oracle's FLANN-style kd-tree (oracle/, OpenMP over queries) on the host
                 cores of this box, same inputs, rank 0 at N = 1 only;
   icp           ICP iterations / s on BASELINE configs[3] (1M source vs 1M target, 30 iterations,
-                source sharded over the ranks, one all-reduce of 24 fp64 sums per iteration).
+                source sharded over the ranks, one all-reduce of 24 fp64 sums per iteration; the
+                loop is device-resident: step kernel, all-reduce and solve kernel are enqueued on
+                one stream, the host reads the result once).
 torch is used for device memory, streams and torch.distributed only.
 """
 import argparse
@@ -234,44 +236,32 @@ def bench_icp(args, capi, torch, dist, world, rank, dev, barrier, max_over_ranks
     iters = args.icp_iters
 
     def run():
-        ctx = capi.IcpShard(tree, src)
-        T_final = np.eye(4, dtype=np.float32)
-        npairs = 0
-        for _ in range(iters):
-            ctx.step_dev(thr, sums.data_ptr(), stream)
-            if world > 1:
-                dist.all_reduce(sums)  # the ONE exchange of an iteration: 24 fp64 sums over xGMI
-            h = sums.cpu().numpy()
-            T = capi.icp_solve(h)
-            ctx.set_transform(T)
-            T_final = T @ T_final
-            npairs = int(h[0])
-        return ctx, T_final, npairs
+        """One align of `iters` iterations, device-resident: step kernel -> (all-reduce) -> solve kernel,
+        enqueued back to back on one stream; the host reads the state once at the end."""
+        ctx = capi.IcpShard(tree, src)  # upload + Morton ordering of the shard: setup, not an iteration
+        barrier()
+        t0 = time.perf_counter()
+        if world == 1:
+            ctx.run_dev(thr, iters, stream)
+        else:
+            for _ in range(iters):
+                ctx.step_dev(thr, sums.data_ptr(), stream)
+                dist.all_reduce(sums)  # the ONE exchange of an iteration: 24 fp64 sums over xGMI (RCCL)
+                ctx.solve_dev(sums.data_ptr(), stream)
+        rc, T_final, st = ctx.state()  # synchronises the stream
+        barrier()
+        dt = time.perf_counter() - t0
+        assert rc == 0 and st.iterations == iters, (rc, st.iterations)
+        ctx.end(want_aligned=False)
+        return dt, T_final, st.last_correspondences
 
-    ctx, _, _ = run()  # warm-up pass (allocations, first-touch)
-    ctx.end(want_aligned=False)
+    run()  # warm-up pass (allocations, first-touch, RCCL channel set-up)
     capi.timing_enable(True)
     capi.timing_read(capi.TIMER_ICP_STEP, reset=True)
-    barrier()
-    ctx = capi.IcpShard(tree, src)  # upload + Morton ordering of the shard: setup, not an iteration
-    barrier()
-    t0 = time.perf_counter()
-    T_final = np.eye(4, dtype=np.float32)
-    npairs = 0
-    for _ in range(iters):
-        ctx.step_dev(thr, sums.data_ptr(), stream)
-        if world > 1:
-            dist.all_reduce(sums)
-        h = sums.cpu().numpy()
-        T = capi.icp_solve(h)
-        ctx.set_transform(T)
-        T_final = T @ T_final
-        npairs = int(h[0])
-    barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
+    dt, T_final, npairs = run()
+    elapsed = max_over_ranks(dt)
     s_ms, s_n = capi.timing_read(capi.TIMER_ICP_STEP, reset=True)
     capi.timing_enable(False)
-    ctx.end(want_aligned=False)
     err = float(np.abs(T_final - T0).max())
     step_ms = s_ms / max(s_n, 1)
     algo = 52 * len(src) + 16 * n  # SURVEY 8d: 52 B / source point + first touch of the target

@@ -267,6 +267,28 @@ int pclmi_icp_solve(const double sums[PCLMI_ICP_NSUMS], float T[16]);
 int pclmi_icp_set_transform(pclmi_icp_ctx *ctx, const float T[16]);
 int pclmi_icp_end(pclmi_icp_ctx *ctx, float *aligned);
 
+/* Device-resident iteration: the same loop with NO host round trip per iteration.  The solve
+ * (centroids, H, 3x3 SVD, T, final = T * final, the convergence criteria of icp.hpp:193-196 and
+ * the min-correspondence check of icp.hpp:103-108) runs as a one-lane kernel on the stream, the
+ * transform stays in device memory for the next step, and once a criterion has fired every later
+ * step / solve of the context is a no-op on the device:
+ *   ctx = pclmi_icp_begin(...); pclmi_icp_set_criteria(ctx, params)   (optional: default = never stop)
+ *   loop: pclmi_icp_step_dev(ctx, thr, d_sums, stream)
+ *         [all-reduce d_sums across ranks on the same stream]
+ *         pclmi_icp_solve_dev(ctx, d_sums, stream)
+ *   pclmi_icp_state(ctx, final_T, stats)                  synchronises and reads the state back
+ *   pclmi_icp_end(ctx, aligned)
+ * pclmi_icp_run_dev enqueues `iterations` x (step, solve) for the single-GPU case.  The device
+ * solve is the code of pclmi_icp_solve compiled for the GPU (IEEE fp64, no contraction): same
+ * sums, same bits.  A context is driven EITHER this way or with pclmi_icp_set_transform.
+ * pclmi_icp_state returns PCLMI_ERR_NOT_ENOUGH when an iteration found fewer pairs than
+ * min_correspondences (final_T / stats are still filled). */
+int pclmi_icp_set_criteria(pclmi_icp_ctx *ctx, const pclmi_icp_params *p);
+int pclmi_icp_solve_dev(pclmi_icp_ctx *ctx, const double *d_sums, void *stream);
+int pclmi_icp_run_dev(pclmi_icp_ctx *ctx, double max_correspondence_distance, int iterations,
+                      void *stream);
+int pclmi_icp_state(pclmi_icp_ctx *ctx, float final_T[16], pclmi_icp_stats *stats);
+
 #ifdef __cplusplus
 }
 #endif

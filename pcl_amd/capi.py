@@ -101,6 +101,10 @@ SIGNATURES = {
     "pclmi_icp_solve": (C.c_int, [c_f64p, c_f32p]),
     "pclmi_icp_set_transform": (C.c_int, [C.c_void_p, c_f32p]),
     "pclmi_icp_end": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pclmi_icp_set_criteria": (C.c_int, [C.c_void_p, C.POINTER(IcpParams)]),
+    "pclmi_icp_solve_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pclmi_icp_run_dev": (C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_void_p]),
+    "pclmi_icp_state": (C.c_int, [C.c_void_p, c_f32p, C.POINTER(IcpStats)]),
 }
 
 
@@ -396,6 +400,25 @@ class IcpShard:
     def set_transform(self, T):
         Tm = np.ascontiguousarray(T, np.float32).reshape(16)
         _check(load_library().pclmi_icp_set_transform(self.h, Tm.ctypes.data_as(c_f32p)))
+
+    # device-resident iteration (no host round trip): see include/pclmi.h
+    def set_criteria(self, params):
+        _check(load_library().pclmi_icp_set_criteria(self.h, C.byref(params)))
+
+    def solve_dev(self, sums_ptr, stream=None):
+        _check(load_library().pclmi_icp_solve_dev(self.h, sums_ptr, stream))
+
+    def run_dev(self, max_correspondence_distance, iterations, stream=None):
+        _check(load_library().pclmi_icp_run_dev(self.h, max_correspondence_distance, iterations, stream))
+
+    def state(self):
+        """Synchronises; returns (status, final_T[4,4], stats)."""
+        T = np.zeros(16, np.float32)
+        st = IcpStats()
+        rc = load_library().pclmi_icp_state(self.h, T.ctypes.data_as(c_f32p), C.byref(st))
+        if rc not in (0, 6):
+            _check(rc)
+        return rc, T.reshape(4, 4), st
 
     def end(self, want_aligned=True):
         out = np.zeros((self.n, 4), np.float32) if want_aligned else None

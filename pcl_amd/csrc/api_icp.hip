@@ -61,6 +61,8 @@ struct pclmi_icp_ctx {
   hipStream_t stream = nullptr;
   hipStream_t user_stream = nullptr;  // stream of the last pclmi_icp_step_dev, when not ours
   double last_thr2 = 0.0;
+  DevBuf<IcpDevState> state;  // device-resident loop state (pclmi_icp_solve_dev)
+  bool dev_mode = false;      // the transform chain lives in `state`, not in T / pending
 };
 
 extern "C" {
@@ -240,7 +242,8 @@ int pclmi_icp_begin(const pclmi_tree *target, const float *src, size_t n_src, si
   {
     WsGuard g(target);
     const int32_t *d_order = nullptr;
-    if ((rc = launch_morton_order(target, g.w, (const float *)raw.p, n_src, 4, lo, hi, c->stream, &d_order)))
+    // stable: the slot order fixes the summation order of the fp64 moments, so it must not vary between runs
+    if ((rc = launch_morton_order(target, g.w, (const float *)raw.p, n_src, 4, lo, hi, c->stream, &d_order, true)))
       return fail(rc);
     if (d_order) {
       if (hipMemcpyAsync(c->order.p, d_order, n_src * 4, hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
@@ -270,6 +273,20 @@ int pclmi_icp_begin(const pclmi_tree *target, const float *src, size_t n_src, si
     return fail(hip_fail(hipGetLastError(), "memset", __FILE__, __LINE__));
   // moments are taken about the centre of the target's bounding box: identical on every rank
   for (int d = 0; d < 3; ++d) c->origin[d] = 0.5 * ((double)target->bb_lo[d] + (double)target->bb_hi[d]);
+  {
+    IcpDevState h;
+    std::memset(&h, 0, sizeof(h));
+    set_identity(h.T);
+    set_identity(h.final_T);
+    if (guess && !is_identity(guess)) std::memcpy(h.final_T, guess, sizeof(h.final_T));  // icp.hpp:63
+    h.max_iterations = INT32_MAX;  // raw stepping: no criterion fires until pclmi_icp_set_criteria
+    h.min_correspondences = 1;
+    h.transformation_epsilon = 0.0;
+    h.euclidean_fitness_epsilon = -std::numeric_limits<double>::max();
+    if ((rc = c->state.alloc(1))) return fail(rc);
+    if (hipMemcpyAsync(c->state.p, &h, sizeof(h), hipMemcpyHostToDevice, c->stream) != hipSuccess)
+      return fail(hip_fail(hipGetLastError(), "state upload", __FILE__, __LINE__));
+  }
   if (hipStreamSynchronize(c->stream) != hipSuccess)
     return fail(hip_fail(hipGetLastError(), "sync", __FILE__, __LINE__));
   *out = c;
@@ -284,7 +301,7 @@ int pclmi_icp_step_dev(pclmi_icp_ctx *c, double max_correspondence_distance, dou
   const double thr2 = max_correspondence_distance * max_correspondence_distance;  // icp.hpp:57
   c->last_thr2 = thr2;
   launch_icp_step(c->tree, c->pts.p, c->n, c->pending, make_xf(c->T), thr2, c->nn.p, c->dist.p, c->origin,
-                  c->partials.p, d_sums, s);
+                  c->partials.p, d_sums, s, c->dev_mode ? c->state.p : nullptr);
   c->pending = false;
   PCLMI_HIP(hipGetLastError());
   return PCLMI_OK;
@@ -298,8 +315,73 @@ int pclmi_icp_step(pclmi_icp_ctx *c, double max_correspondence_distance, double 
   return PCLMI_OK;
 }
 
+// ---- device-resident iteration -----------------------------------------------------------------
+int pclmi_icp_set_criteria(pclmi_icp_ctx *c, const pclmi_icp_params *p) {
+  PCLMI_CHECK(c && p, PCLMI_ERR_INVALID, "NULL argument");
+  PCLMI_CHECK(!c->dev_mode, PCLMI_ERR_INVALID, "criteria must be set before the first pclmi_icp_solve_dev");
+  PCLMI_HIP(hipSetDevice(c->tree->device));
+  IcpDevState h;
+  PCLMI_HIP(hipMemcpy(&h, c->state.p, sizeof(h), hipMemcpyDeviceToHost));
+  h.max_iterations = p->max_iterations;
+  h.min_correspondences = p->min_correspondences;
+  h.transformation_epsilon = p->transformation_epsilon;
+  h.euclidean_fitness_epsilon = p->euclidean_fitness_epsilon;
+  PCLMI_HIP(hipMemcpy(c->state.p, &h, sizeof(h), hipMemcpyHostToDevice));
+  return PCLMI_OK;
+}
+
+int pclmi_icp_solve_dev(pclmi_icp_ctx *c, const double *d_sums, void *stream) {
+  PCLMI_CHECK(c && d_sums, PCLMI_ERR_INVALID, "NULL argument");
+  PCLMI_CHECK(!c->pending, PCLMI_ERR_INVALID,
+              "pclmi_icp_solve_dev after pclmi_icp_set_transform: one context is driven either from the host or "
+              "from the device");
+  PCLMI_HIP(hipSetDevice(c->tree->device));
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  c->user_stream = stream ? s : nullptr;
+  c->dev_mode = true;
+  launch_icp_solve(d_sums, c->state.p, s);
+  PCLMI_HIP(hipGetLastError());
+  return PCLMI_OK;
+}
+
+int pclmi_icp_run_dev(pclmi_icp_ctx *c, double max_correspondence_distance, int iterations, void *stream) {
+  PCLMI_CHECK(c, PCLMI_ERR_INVALID, "NULL argument");
+  for (int i = 0; i < iterations; ++i) {
+    RC(pclmi_icp_step_dev(c, max_correspondence_distance, c->sums.p, stream));
+    RC(pclmi_icp_solve_dev(c, c->sums.p, stream));
+  }
+  return PCLMI_OK;
+}
+
+int pclmi_icp_state(pclmi_icp_ctx *c, float final_T[16], pclmi_icp_stats *stats) {
+  PCLMI_CHECK(c, PCLMI_ERR_INVALID, "NULL argument");
+  PCLMI_HIP(hipSetDevice(c->tree->device));
+  hipStream_t s = c->user_stream ? c->user_stream : c->stream;
+  IcpDevState h;
+  PCLMI_HIP(hipMemcpyAsync(&h, c->state.p, sizeof(h), hipMemcpyDeviceToHost, s));
+  PCLMI_HIP(hipStreamSynchronize(s));
+  if (final_T) std::memcpy(final_T, h.final_T, sizeof(h.final_T));
+  if (stats) {
+    stats->iterations = h.iterations;
+    stats->converged = h.converged;
+    stats->last_correspondences = h.last_pairs;
+    stats->last_inliers = h.last_pairs;
+    stats->fitness_delta = h.fit;
+    stats->transform_delta = h.tdelta;
+  }
+  if (h.status == PCLMI_ERR_NOT_ENOUGH) {
+    set_error("not enough correspondences (%d < the configured minimum): relax the threshold parameters",
+              h.last_pairs);
+    return PCLMI_ERR_NOT_ENOUGH;
+  }
+  return PCLMI_OK;
+}
+
 int pclmi_icp_set_transform(pclmi_icp_ctx *c, const float T[16]) {
   PCLMI_CHECK(c && T, PCLMI_ERR_INVALID, "NULL argument");
+  PCLMI_CHECK(!c->dev_mode, PCLMI_ERR_INVALID,
+              "pclmi_icp_set_transform after pclmi_icp_solve_dev: one context is driven either from the host or "
+              "from the device");
   if (c->pending) {  // two transforms without a step in between: apply the first one now
     PCLMI_HIP(hipSetDevice(c->tree->device));
     if (c->user_stream) PCLMI_HIP(hipStreamSynchronize(c->user_stream));
@@ -318,6 +400,7 @@ int pclmi_icp_end(pclmi_icp_ctx *c, float *aligned) {
   if (c->user_stream) (void)hipStreamSynchronize(c->user_stream);  // steps enqueued on the caller's stream
   if (aligned && c->n) {
     if (c->pending) launch_transform(c->pts.p, c->n, make_xf(c->T), c->stream);
+    if (c->dev_mode) launch_transform_pending(c->pts.p, c->n, c->state.p, c->stream);
     DevBuf<float4> outb;
     rc = outb.alloc(c->n);
     if (!rc) {
@@ -529,6 +612,25 @@ int pclmi_icp_align(const pclmi_icp_params *p, const pclmi_tree *target, const f
   pclmi_icp_ctx *c = nullptr;
   RC(pclmi_icp_begin(target, src, n_src, stride_bytes, guess, &c));
   if (guess && !is_identity(guess)) std::memcpy(final_T, guess, 16 * sizeof(float));  // icp.hpp:63
+  if (p->ransac_iterations <= 0) {
+    // no RANSAC step: the whole loop runs on the device (step -> reduce -> solve, back to back on one stream);
+    // the host only looks at the state every few iterations to stop enqueueing once a criterion has fired
+    // (iterations enqueued past that point are no-ops on the device)
+    int rc = pclmi_icp_set_criteria(c, p);
+    pclmi_icp_stats st;
+    std::memset(&st, 0, sizeof(st));
+    int enqueued = 0;
+    while (!rc) {
+      const int chunk = std::max(1, std::min(8, p->max_iterations - enqueued));
+      if ((rc = pclmi_icp_run_dev(c, p->max_correspondence_distance, chunk, nullptr))) break;
+      enqueued += chunk;
+      rc = pclmi_icp_state(c, final_T, &st);
+      if (st.converged) break;
+    }
+    if (stats) *stats = st;
+    int rc2 = pclmi_icp_end(c, aligned);
+    return rc ? rc : rc2;
+  }
   float T[16], Tprev[16];
   set_identity(T);
   RansacScratch rs;

@@ -15,6 +15,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include "pclmi_internal.h"
+#include "rigid_solve.hpp"
 #include "traverse.hpp"
 
 namespace pclmi {
@@ -104,8 +105,15 @@ __global__ __launch_bounds__(64 * ICP_WPB) void icp_step_kernel(TreeView t, floa
                                                                  const float4 *__restrict__ cloud,
                                                                  int *__restrict__ nn_idx,
                                                                  float *__restrict__ dist, double ox, double oy,
-                                                                 double oz, double *__restrict__ partials) {
+                                                                 double oz, double *__restrict__ partials,
+                                                                 const IcpDevState *__restrict__ st) {
   __shared__ double lds[ICP_WPB][NS];
+  if (st) {  // device-resident loop: the pending transform and the stop flag live in device memory
+    if (st->done) return;
+    apply = st->apply;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) T.m[j] = st->T[j];
+  }
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
   const int per = (gridDim.x + 7) >> 3;
@@ -160,10 +168,16 @@ __global__ __launch_bounds__(64 * ICP_WPB) void icp_step_kernel(TreeView t, floa
 }
 
 // fixed-order sum of the block partials: block j of the grid produces out[j]
+// st (nullable): the step before this pass has consumed the pending transform of the device state
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const double *__restrict__ partials, int nrows,
-                                                              int nv, double *__restrict__ out) {
+                                                              int nv, double *__restrict__ out,
+                                                              IcpDevState *__restrict__ st = nullptr) {
   __shared__ double sh[256];
   const int j = blockIdx.x;
+  if (st) {
+    if (st->done) return;  // block-uniform
+    if (j == 0 && threadIdx.x == 0) st->apply = 0;
+  }
   double s = 0.0;
   for (int r = threadIdx.x; r < nrows; r += 256) s += partials[(size_t)r * nv + j];
   sh[threadIdx.x] = s;
@@ -174,6 +188,65 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double *__re
   }
   if (threadIdx.x == 0) out[j] = sh[0];
 }
+
+// One lane turns the (all-reduced) sums into the next transform and evaluates the convergence criteria
+// (icp.hpp:103-108,171-196): the device-side twin of the loop body of pclmi_icp_align.
+__global__ __launch_bounds__(64) void icp_solve_kernel(const double *__restrict__ sums, IcpDevState *__restrict__ st) {
+  if (threadIdx.x != 0 || st->done) return;
+  double h[NS];
+#pragma unroll
+  for (int j = 0; j < NS; ++j) h[j] = sums[j];
+  const long long cnt = llround(h[0]);
+  st->last_pairs = (int)cnt;
+  if (cnt < (long long)st->min_correspondences) {  // icp.hpp:103-108
+    st->status = PCLMI_ERR_NOT_ENOUGH;
+    st->done = 1;
+    return;
+  }
+  float Tprev[16], T[16], F[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    Tprev[i] = st->T[i];
+    F[i] = st->final_T[i];
+  }
+  if (!rs::solve_from_sums(h, T)) {
+    st->status = PCLMI_ERR_NOT_ENOUGH;
+    st->done = 1;
+    return;
+  }
+  rs::mat4_mul(T, F, F);  // icp.hpp:177
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    st->T[i] = T[i];
+    st->final_T[i] = F[i];
+  }
+  st->apply = 1;  // icp.hpp:174, carried out by the next step (or at the end)
+  const int it = st->iterations + 1;
+  st->iterations = it;
+  const double tdelta = (double)rs::transform_delta(T, Tprev);
+  const double n_points = h[18] > 0 ? h[18] : 1.0;
+  const double fit = h[17] / n_points;  // registration.hpp:60-68
+  st->tdelta = tdelta;
+  st->fit = fit;
+  if (it >= st->max_iterations || tdelta < st->transformation_epsilon ||
+      fabs(fit) <= st->euclidean_fitness_epsilon) {  // icp.hpp:193-196
+    st->converged = 1;
+    st->done = 1;
+  }
+}
+
+__global__ void transform_pending_kernel(float4 *__restrict__ pts, int n, const IcpDevState *__restrict__ st) {
+  if (!st->apply) return;
+  Xf T;
+#pragma unroll
+  for (int j = 0; j < 12; ++j) T.m[j] = st->T[j];
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 p = pts[i];
+  if (finite3(p)) pts[i] = apply_xf(T, p);
+}
+
+__global__ void clear_apply_kernel(IcpDevState *st) { st->apply = 0; }
 
 // sums over explicitly paired points (TransformationEstimationSVD on a correspondence list,
 // impl/transformation_estimation_svd.hpp:101-111; also the RANSAC inlier refit)
@@ -328,6 +401,15 @@ void launch_transform(float4 *d_pts, size_t n, const Xf &T, hipStream_t s) {
   if (n) hipLaunchKernelGGL(transform_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, d_pts, (int)n, T);
 }
 
+void launch_transform_pending(float4 *d_pts, size_t n, IcpDevState *st, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(transform_pending_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, d_pts, (int)n, st);
+  hipLaunchKernelGGL(clear_apply_kernel, dim3(1), dim3(1), 0, s, st);
+}
+
+void launch_icp_solve(const double *d_sums, IcpDevState *st, hipStream_t s) {
+  hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(64), 0, s, d_sums, st);
+}
+
 void launch_pack(const float *d_in, size_t stride_f, const int *d_rows, size_t n, float4 *d_out, hipStream_t s) {
   if (n)
     hipLaunchKernelGGL(pack_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, d_in, (int)stride_f, d_rows, (int)n,
@@ -350,15 +432,15 @@ unsigned icp_step_blocks(size_t n) {
 
 void launch_icp_step(const pclmi_tree *t, float4 *d_pts, size_t n, bool apply, const Xf &T, double thr2,
                      int *d_nn, float *d_dist, const double origin[3], double *d_partials, double *d_sums,
-                     hipStream_t s) {
+                     hipStream_t s, IcpDevState *st) {
   const unsigned blocks = icp_step_blocks(n);
   {
     TimingScope ts(PCLMI_TIMER_ICP_STEP, s);
     hipLaunchKernelGGL(icp_step_kernel, dim3(blocks), dim3(64 * ICP_WPB), 0, s, t->view(), d_pts, (int)n,
                        apply ? 1 : 0, T, (float)thr2, thr2, (const float4 *)t->d_cloud, d_nn, d_dist, origin[0],
-                       origin[1], origin[2], d_partials);
+                       origin[1], origin[2], d_partials, (const IcpDevState *)st);
   }
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(NS), dim3(256), 0, s, d_partials, (int)blocks, NS, d_sums);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(NS), dim3(256), 0, s, d_partials, (int)blocks, NS, d_sums, st);
 }
 
 unsigned pair_reduce_blocks(size_t n) {
@@ -372,14 +454,16 @@ void launch_pair_reduce(const float4 *src, const int *sidx, const float4 *tgt, c
   const unsigned blocks = pair_reduce_blocks(n);
   hipLaunchKernelGGL(pair_reduce_kernel, dim3(blocks), dim3(64 * PR_WPB), 0, s, src, sidx, tgt, tidx, flags, (int)n,
                      origin[0], origin[1], origin[2], d_partials);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(NS), dim3(256), 0, s, d_partials, (int)blocks, NS, d_sums);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(NS), dim3(256), 0, s, d_partials, (int)blocks, NS, d_sums,
+                     (IcpDevState *)nullptr);
 }
 
 void launch_moment_reduce(const float4 *src, const int *sidx, size_t n, double *d_partials, double *d_sums,
                           hipStream_t s) {
   const unsigned blocks = pair_reduce_blocks(n);
   hipLaunchKernelGGL(moment_reduce_kernel, dim3(blocks), dim3(64 * PR_WPB), 0, s, src, sidx, (int)n, d_partials);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(NS), dim3(256), 0, s, d_partials, (int)blocks, NS, d_sums);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(NS), dim3(256), 0, s, d_partials, (int)blocks, NS, d_sums,
+                     (IcpDevState *)nullptr);
 }
 
 void launch_count_within(const float4 *src, const int *sidx, const float4 *tgt, const int *tidx, size_t n,

@@ -394,7 +394,7 @@ __global__ void cell_scatter_kernel(const unsigned int *__restrict__ cell, const
 
 int launch_morton_order(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq,
                         size_t q_stride_f, const float *bb_lo, const float *bb_hi, hipStream_t s,
-                        const int32_t **d_order) {
+                        const int32_t **d_order, bool stable) {
   if (!bb_lo) bb_lo = t->bb_lo;
   if (!bb_hi) bb_hi = t->bb_hi;
   *d_order = nullptr;
@@ -417,6 +417,22 @@ int launch_morton_order(const pclmi_tree *t, Workspace *w, const float *d_q, siz
   const unsigned grid = (unsigned)((nq + 255) / 256);
   hipLaunchKernelGGL(cell_count_kernel, dim3(grid), dim3(256), 0, s, d_q, (int)q_stride_f, (int)nq,
                      bb_lo[0], bb_lo[1], bb_lo[2], sc[0], sc[1], sc[2], 30 - bits, w->keys_in, w->ranks, w->hist);
+  if (stable) {
+    // Reproducible order (ICP: the order fixes the summation order of the fp64 moments): a stable radix
+    // sort of (cell, row) pairs instead of the atomic ranks, whose order inside a cell varies from run to run.
+    launch_iota((int *)w->ranks, nq, s);
+    size_t need = 0;
+    PCLMI_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, need, (const unsigned int *)w->keys_in, (unsigned int *)nullptr,
+                                                 (const int *)w->ranks, (int *)w->vals_out, (int)nq, 0, bits, s));
+    const size_t keys_bytes = (nq * sizeof(unsigned int) + 255) & ~(size_t)255;
+    rc = w->ensure_scratch(keys_bytes + need);
+    if (rc) return rc;
+    PCLMI_HIP(hipcub::DeviceRadixSort::SortPairs((char *)w->scratch + keys_bytes, need, (const unsigned int *)w->keys_in,
+                                                 (unsigned int *)w->scratch, (const int *)w->ranks, (int *)w->vals_out,
+                                                 (int)nq, 0, bits, s));
+    *d_order = w->vals_out;
+    return PCLMI_OK;
+  }
   size_t tmp = w->cap_tmp;
   PCLMI_HIP(hipcub::DeviceScan::ExclusiveSum(w->sort_tmp, tmp, w->hist, w->hist, (int)nbins, s));
   hipLaunchKernelGGL(cell_scatter_kernel, dim3(grid), dim3(256), 0, s, w->keys_in, w->ranks, (int)nq, w->hist,

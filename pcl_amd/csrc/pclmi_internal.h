@@ -150,10 +150,11 @@ void build_host_tree(const float *pts, const int32_t *ext, size_t n, HostTree *o
 
 // ---- kernels launchers (knn_kernels.hip) -------------------------------------------------
 // order: nullable device permutation (sorted slot -> query row).  bb_lo / bb_hi: box the Morton
-// cells are laid over (NULL = the tree's bounding box).
+// cells are laid over (NULL = the tree's bounding box).  stable: rows of one cell keep their input order
+// (reproducible from run to run; the default ranks them with an atomic counter, which is faster).
 int launch_morton_order(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq,
                         size_t q_stride_f, const float *bb_lo, const float *bb_hi, hipStream_t s,
-                        const int32_t **d_order);
+                        const int32_t **d_order, bool stable = false);
 int launch_knn(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, size_t q_stride_f,
                const int32_t *d_order, int k_eff, int32_t *d_idx, float *d_d2, hipStream_t s);
 
@@ -177,14 +178,32 @@ inline Xf make_xf(const float T[16]) {
   for (int i = 0; i < 12; ++i) x.m[i] = T[i];
   return x;
 }
+// Device-resident state of one ICP context: lets the iteration run without a host round trip
+// (pclmi_icp_solve_dev).  Written by icp_solve_kernel, read by icp_step_kernel.
+struct IcpDevState {
+  float T[16];        // transform of the last solve; applied by the next step (or at the end) while `apply`
+  float final_T[16];  // accumulated transform (icp.hpp:177), starts as the guess
+  int apply;          // T waits to be applied
+  int done;           // converged or failed: later steps and solves are no-ops
+  int status;         // PCLMI_OK / PCLMI_ERR_NOT_ENOUGH
+  int iterations;
+  int converged;
+  int last_pairs;
+  int max_iterations, min_correspondences;
+  double fit, tdelta;
+  double transformation_epsilon, euclidean_fitness_epsilon;
+};
 void launch_transform(float4 *d_pts, size_t n, const Xf &T, hipStream_t s);
+void launch_transform_pending(float4 *d_pts, size_t n, IcpDevState *st, hipStream_t s);  // applies st->T iff st->apply
+void launch_icp_solve(const double *d_sums, IcpDevState *st, hipStream_t s);
 void launch_pack(const float *d_in, size_t stride_f, const int *d_rows, size_t n, float4 *d_out, hipStream_t s);
 void launch_permute(const float4 *in, const int *order, size_t n, float4 *out, hipStream_t s);
 void launch_unpermute(const float4 *in, const int *order, size_t n, float4 *out, hipStream_t s);
 unsigned icp_step_blocks(size_t n);
+// st (nullable): take the pending transform from the device-side state instead of apply / T
 void launch_icp_step(const pclmi_tree *t, float4 *d_pts, size_t n, bool apply, const Xf &T, double thr2,
                      int *d_nn, float *d_dist, const double origin[3], double *d_partials, double *d_sums,
-                     hipStream_t s);
+                     hipStream_t s, IcpDevState *st = nullptr);
 unsigned pair_reduce_blocks(size_t n);
 void launch_pair_reduce(const float4 *src, const int *sidx, const float4 *tgt, const int *tidx,
                         const unsigned char *flags, size_t n, const double origin[3], double *d_partials,

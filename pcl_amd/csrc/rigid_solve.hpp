@@ -1,0 +1,205 @@
+// rigid_solve.hpp - the O(1) tail of TransformationEstimationSVD
+// (registration/include/pcl/registration/impl/transformation_estimation_svd.hpp:114-168) as
+// host+device inline functions: ONE source for pclmi_icp_solve (host) and icp_solve_kernel (device),
+// compiled with -ffp-contract=off on both sides and using only IEEE +,-,*,/,sqrt in fp64, so the two
+// produce the same bits from the same sums.
+//
+// The reference does this in fp32 with a two-pass demean; here the sums arrive as one-pass fp64
+// moments about a common origin, H = S_st - S_s S_t' / n, and the 3x3 SVD runs in fp64 - at least as
+// accurate as the reference, within its 1e-5 tolerance.
+#ifndef PCLMI_RIGID_SOLVE_HPP_
+#define PCLMI_RIGID_SOLVE_HPP_
+
+#include <hip/hip_runtime.h>
+
+#include "pclmi.h"
+
+namespace pclmi {
+namespace rs {
+
+#define PCLMI_HD __host__ __device__ inline
+
+// One rotation of the one-sided Jacobi SVD on columns P, Q (compile-time indices: everything stays in
+// registers on the GPU - a run-time index would put the matrices into scratch memory).
+template <int P, int Q>
+PCLMI_HD bool jacobi_rotate(double (&a)[9], double (&v)[9]) {
+  double alpha = 0, beta = 0, gamma = 0;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    alpha += a[r * 3 + P] * a[r * 3 + P];
+    beta += a[r * 3 + Q] * a[r * 3 + Q];
+    gamma += a[r * 3 + P] * a[r * 3 + Q];
+  }
+  // columns orthogonal to a few fp64 roundings: the rounding error of gamma itself is ~eps * sqrt(alpha * beta),
+  // a tighter test would keep rotating by noise until the sweep limit
+  if (gamma == 0.0 || fabs(gamma) <= 1e-15 * sqrt(alpha * beta)) return false;
+  const double zeta = (beta - alpha) / (2.0 * gamma);
+  const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+  const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    double x = a[r * 3 + P], y = a[r * 3 + Q];
+    a[r * 3 + P] = c * x - s * y;
+    a[r * 3 + Q] = s * x + c * y;
+    x = v[r * 3 + P];
+    y = v[r * 3 + Q];
+    v[r * 3 + P] = c * x - s * y;
+    v[r * 3 + Q] = s * x + c * y;
+  }
+  return true;
+}
+
+// exchange columns I and J of (s, a, v) when s[J] > s[I]
+template <int I, int J>
+PCLMI_HD void order_columns(double (&s)[3], double (&a)[9], double (&v)[9]) {
+  if (s[J] > s[I]) {
+    double t = s[I];
+    s[I] = s[J];
+    s[J] = t;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      t = a[r * 3 + I];
+      a[r * 3 + I] = a[r * 3 + J];
+      a[r * 3 + J] = t;
+      t = v[r * 3 + I];
+      v[r * 3 + I] = v[r * 3 + J];
+      v[r * 3 + J] = t;
+    }
+  }
+}
+
+// one-sided Jacobi SVD of a 3x3, singular values descending (as Eigen::JacobiSVD orders them, so
+// that "column 2" of the determinant fix is the smallest singular direction).  A = U diag(S) V'.
+PCLMI_HD void svd3(const double A[9], double U[9], double S[3], double V[9]) {
+  double a[9], v[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+#pragma unroll
+  for (int i = 0; i < 9; ++i) a[i] = A[i];
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    bool rotated = jacobi_rotate<0, 1>(a, v);
+    rotated |= jacobi_rotate<0, 2>(a, v);
+    rotated |= jacobi_rotate<1, 2>(a, v);
+    if (!rotated) break;
+  }
+  double s[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) s[c] = sqrt(a[c] * a[c] + a[3 + c] * a[3 + c] + a[6 + c] * a[6 + c]);
+  order_columns<0, 1>(s, a, v);
+  order_columns<0, 2>(s, a, v);
+  order_columns<1, 2>(s, a, v);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    S[c] = s[c];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      V[r * 3 + c] = v[r * 3 + c];
+      U[r * 3 + c] = S[c] > 0.0 ? a[r * 3 + c] / S[c] : 0.0;
+    }
+  }
+  // rank-deficient H (three-point RANSAC samples are rank 2): complete U to an orthonormal basis,
+  // which is what ComputeFullU returns.
+  const double tiny = S[0] * 1e-13;
+  if (S[2] <= tiny) {
+    double u0[3] = {U[0], U[3], U[6]};
+    if (S[0] <= 0.0) {
+      u0[0] = 1; u0[1] = 0; u0[2] = 0;
+      U[0] = 1; U[3] = 0; U[6] = 0;
+    }
+    if (S[1] <= tiny) {
+      int m = fabs(u0[1]) < fabs(u0[0]) ? 1 : 0;  // the axis u0 is least aligned with
+      if (fabs(u0[2]) < fabs(m ? u0[1] : u0[0])) m = 2;
+      const double e[3] = {m == 0 ? 1.0 : 0.0, m == 1 ? 1.0 : 0.0, m == 2 ? 1.0 : 0.0};
+      double w[3] = {u0[1] * e[2] - u0[2] * e[1], u0[2] * e[0] - u0[0] * e[2], u0[0] * e[1] - u0[1] * e[0]};
+      const double nw = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) w[d] /= nw;
+      U[1] = w[0]; U[4] = w[1]; U[7] = w[2];
+    }
+    const double u1[3] = {U[1], U[4], U[7]};
+    U[2] = u0[1] * u1[2] - u0[2] * u1[1];
+    U[5] = u0[2] * u1[0] - u0[0] * u1[2];
+    U[8] = u0[0] * u1[1] - u0[1] * u1[0];
+  }
+}
+
+PCLMI_HD double det3(const double M[9]) {
+  return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) +
+         M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+
+// sums layout: pclmi.h (PCLMI_ICP_NSUMS).  Returns false (T = identity) when there is no pair.
+PCLMI_HD bool solve_from_sums(const double *sums, float T[16]) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.f : 0.f;
+  const double n = sums[0];
+  if (!(n >= 1.0)) return false;
+  double o[3] = {0, 0, 0};
+  if (sums[18] > 0.0) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) o[d] = sums[19 + d] / sums[18];
+  }
+  double ms[3], mt[3];  // centroids relative to the origin
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    ms[d] = sums[1 + d] / n;
+    mt[d] = sums[4 + d] / n;
+  }
+  double H[9];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) H[r * 3 + c] = sums[7 + r * 3 + c] - n * ms[r] * mt[c];
+  double U[9], S[3], V[9];
+  svd3(H, U, S, V);
+  if (det3(U) * det3(V) < 0) {  // transformation_estimation_svd.hpp:156-160
+#pragma unroll
+    for (int r = 0; r < 3; ++r) V[r * 3 + 2] = -V[r * 3 + 2];
+  }
+  double R[9];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      double s = 0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) s += V[r * 3 + k] * U[c * 3 + k];  // V * U'
+      R[r * 3 + c] = s;
+    }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    double rc = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) rc += R[r * 3 + c] * (ms[c] + o[c]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) T[r * 4 + c] = (float)R[r * 3 + c];
+    T[r * 4 + 3] = (float)((mt[r] + o[r]) - rc);  // t = ct - R cs
+  }
+  return true;
+}
+
+// C = A * B (row-major 4x4, fp32, k ascending); C may alias A or B
+PCLMI_HD void mat4_mul(const float A[16], const float B[16], float C[16]) {
+  float R[16];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s += A[r * 4 + k] * B[k * 4 + c];
+      R[r * 4 + c] = s;
+    }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) C[i] = R[i];
+}
+
+// sum |T - Tprev| in fp32 (the Eigen expression of icp.hpp:194)
+PCLMI_HD float transform_delta(const float T[16], const float Tprev[16]) {
+  float fs = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) fs += fabsf(T[i] - Tprev[i]);
+  return fs;
+}
+
+}  // namespace rs
+}  // namespace pclmi
+#endif

@@ -6,6 +6,11 @@ fused GPU step on its shard (pclmi_icp_step_dev), the 24 fp64 partial sums are c
 all-reduce per iteration (RCCL when the process group is "nccl"; gloo on CPU in the tests), and every
 rank runs the identical host solve (pclmi_icp_solve), so all ranks hold bit-identical transforms with
 no broadcast.  torch is plumbing here: the sums buffer and the collective.
+
+icp_align_gpu_sharded_dev is the same loop with NO host round trip per iteration: the solve runs as a
+kernel on the stream (pclmi_icp_solve_dev - the same code compiled for the GPU, same bits), the
+all-reduce is enqueued between step and solve, and the host looks at the device-side state only every
+`check_every` iterations (iterations enqueued after a criterion fired are no-ops on the device).
 """
 import numpy as np
 
@@ -86,3 +91,39 @@ def icp_align_gpu_sharded(target_tree, src_shard, params, guess=None, group=None
     rc, T, it, ok, pairs = icp_align_sharded(step, ctx.set_transform, params, guess, group)
     aligned = ctx.end()
     return rc, T, aligned, it, ok, pairs
+
+
+def icp_align_gpu_sharded_dev(target_tree, src_shard, params, guess=None, group=None, check_every=8):
+    """Device-resident variant of icp_align_gpu_sharded: same results, one host sync per `check_every`
+    iterations.  Runs on torch's current stream (the collective is ordered on it too)."""
+    import torch
+    import torch.distributed as dist
+    ctx = capi.IcpShard(target_tree, src_shard, guess)
+    ctx.set_criteria(params)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    sums = torch.zeros(capi.ICP_NSUMS, dtype=torch.float64, device=dev)
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    cur = torch.cuda.current_stream()
+    own = None
+    if not cur.cuda_stream:
+        # the legacy null stream: the library would fall back to its own stream; use an explicit one instead
+        own = torch.cuda.Stream(device=dev)
+        own.wait_stream(cur)
+    with torch.cuda.stream(own if own is not None else cur):
+        s = torch.cuda.current_stream().cuda_stream
+        enqueued = 0
+        while True:
+            chunk = max(1, min(check_every, params.max_iterations - enqueued))
+            for _ in range(chunk):
+                ctx.step_dev(params.max_correspondence_distance, sums.data_ptr(), s)
+                if multi:
+                    dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+                ctx.solve_dev(sums.data_ptr(), s)
+            enqueued += chunk
+            rc, T, st = ctx.state()
+            if rc or st.converged:
+                break
+        aligned = ctx.end()
+    if own is not None:
+        cur.wait_stream(own)
+    return rc, T, aligned, st.iterations, bool(st.converged), st.last_correspondences

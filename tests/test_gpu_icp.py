@@ -248,3 +248,51 @@ def test_sharded_driver_single_rank_equals_icp_align(capi, orc):
     rc2, T2, out2, it, ok, pairs = sharded.icp_align_gpu_sharded(tt, src, p)
     assert rc == rc2 == 0 and ok and it == st.iterations and pairs == st.last_correspondences
     assert np.array_equal(T, T2) and np.array_equal(out, out2)
+
+
+def test_device_resident_loop_equals_host_driven_loop(capi, orc):
+    """pclmi_icp_solve_dev / run_dev (solve as a kernel, no host round trip) == the host-driven loop
+    (pclmi_icp_step + pclmi_icp_solve + pclmi_icp_set_transform), bit for bit."""
+    from pcl_amd import sharded
+    tgt = surface_cloud(60000, 71)
+    T0 = rigid(1.5, (1, 0, 1), (0.3, 0.1, -0.2))
+    src = orc.transform(tgt[::2], np.linalg.inv(T0))
+    tt = capi.Tree(tgt)
+    p = capi.icp_default_params()
+    p.ransac_iterations = 0
+    for max_it, teps, guess in [(7, 0.0, None), (60, 1e-5, rigid(1.0, (1, 0, 1), (0.2, 0.1, -0.1)))]:
+        p.max_iterations, p.transformation_epsilon, p.max_correspondence_distance = max_it, teps, 2.0
+        rc1, T1, out1, it1, ok1, pairs1 = sharded.icp_align_gpu_sharded(tt, src, p, guess=guess)
+        rc2, T2, out2, it2, ok2, pairs2 = sharded.icp_align_gpu_sharded_dev(tt, src, p, guess=guess, check_every=3)
+        rc3, T3, out3, st3 = capi.icp_align(tt, src, p, guess=guess)
+        assert rc1 == rc2 == rc3 == 0 and ok1 and ok2 and st3.converged
+        assert it1 == it2 == st3.iterations and pairs1 == pairs2 == st3.last_correspondences
+        if teps:
+            assert it1 < max_it
+        assert np.array_equal(T1, T2) and np.array_equal(T1, T3)
+        assert np.array_equal(out1, out2) and np.array_equal(out1, out3)
+    # raw stepping without criteria: run_dev never stops by itself; state can be read any time
+    ctx = capi.IcpShard(tt, src)
+    ctx.run_dev(2.0, 5)
+    rc, Ta, st = ctx.state()
+    assert rc == 0 and st.iterations == 5 and not st.converged
+    ctx.run_dev(2.0, 2)
+    rc, Tb, st = ctx.state()
+    assert st.iterations == 7
+    p.max_iterations, p.transformation_epsilon = 7, 0.0
+    rc1, T1, out1, it1, ok1, pairs1 = sharded.icp_align_gpu_sharded(tt, src, p)
+    assert np.array_equal(Tb, T1) and np.array_equal(ctx.end(), out1)
+    # not enough correspondences is latched on the device and reported by the state read
+    ctx = capi.IcpShard(tt, src + np.float32(1e4))
+    p.max_correspondence_distance = 1.0
+    ctx.set_criteria(p)
+    ctx.run_dev(1.0, 4)
+    rc, T, st = ctx.state()
+    assert rc == 6 and not st.converged and st.iterations == 0 and np.array_equal(T, np.eye(4, dtype=np.float32))
+    ctx.end(want_aligned=False)
+    # a context is driven from the host or from the device, not both
+    ctx = capi.IcpShard(tt, src)
+    ctx.run_dev(2.0, 1)
+    with pytest.raises(capi.PclmiError):
+        ctx.set_transform(np.eye(4, dtype=np.float32))
+    ctx.end(want_aligned=False)
