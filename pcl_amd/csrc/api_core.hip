@@ -64,6 +64,14 @@ TimingScope::~TimingScope() {
   g_pending.push_back(r);
 }
 
+bool nn1_per_lane() {
+  static const bool v = [] {
+    const char *e = getenv("PCLMI_NN1");
+    return !(e && e[0] == 'u');
+  }();
+  return v;
+}
+
 // ---- result-buffer cache ------------------------------------------------------------------------
 // hipMalloc / hipFree cost ~0.1 ms each and hipFree synchronises the device; the variable-length
 // results of pclmi_radius_dev are therefore recycled: pclmi_free_dev parks up to kCacheSlots buffers

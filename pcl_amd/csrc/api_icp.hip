@@ -52,6 +52,7 @@ struct pclmi_icp_ctx {
   DevBuf<int> order;      // slot -> original row
   DevBuf<int> inv;        // original row -> slot
   DevBuf<int> nn;         // per slot: index of the nearest target row (-1: not searchable)
+  DevBuf<int> nn_slot;    // per slot: bucket slot of that row (start bound of the next step's search)
   DevBuf<float> dist;     // per slot: min(d2, thr2) of the previous step (correspondence_distances_)
   DevBuf<double> partials;
   DevBuf<double> sums;
@@ -61,6 +62,7 @@ struct pclmi_icp_ctx {
   hipStream_t stream = nullptr;
   hipStream_t user_stream = nullptr;  // stream of the last pclmi_icp_step_dev, when not ours
   double last_thr2 = 0.0;
+  bool stepped = false;       // nn holds the neighbours of a previous step
   DevBuf<IcpDevState> state;  // device-resident loop state (pclmi_icp_solve_dev)
   bool dev_mode = false;      // the transform chain lives in `state`, not in T / pending
 };
@@ -235,7 +237,7 @@ int pclmi_icp_begin(const pclmi_tree *target, const float *src, size_t n_src, si
   }
   if (!(lo[0] <= hi[0])) lo[0] = lo[1] = lo[2] = hi[0] = hi[1] = hi[2] = 0.f;
   if ((rc = c->pts.alloc(n_src)) || (rc = c->order.alloc(n_src)) || (rc = c->inv.alloc(n_src)) ||
-      (rc = c->nn.alloc(n_src)) || (rc = c->dist.alloc(n_src)) ||
+      (rc = c->nn.alloc(n_src)) || (rc = c->nn_slot.alloc(n_src)) || (rc = c->dist.alloc(n_src)) ||
       (rc = c->partials.alloc((size_t)std::max(icp_step_blocks(n_src), pair_reduce_blocks(n_src)) * PCLMI_ICP_NSUMS)) ||
       (rc = c->sums.alloc(PCLMI_ICP_NSUMS)))
     return fail(rc);
@@ -300,9 +302,10 @@ int pclmi_icp_step_dev(pclmi_icp_ctx *c, double max_correspondence_distance, dou
   c->user_stream = stream ? s : nullptr;
   const double thr2 = max_correspondence_distance * max_correspondence_distance;  // icp.hpp:57
   c->last_thr2 = thr2;
-  launch_icp_step(c->tree, c->pts.p, c->n, c->pending, make_xf(c->T), thr2, c->nn.p, c->dist.p, c->origin,
-                  c->partials.p, d_sums, s, c->dev_mode ? c->state.p : nullptr);
+  launch_icp_step(c->tree, c->pts.p, c->n, c->pending, make_xf(c->T), thr2, c->nn.p, c->nn_slot.p, c->dist.p, c->origin,
+                  c->partials.p, d_sums, s, c->dev_mode ? c->state.p : nullptr, c->stepped);
   c->pending = false;
+  c->stepped = true;
   PCLMI_HIP(hipGetLastError());
   return PCLMI_OK;
 }

@@ -96,17 +96,38 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[NV], double (*l
   }
 }
 
+// wave sum of N doubles (lanes with use == false contribute zero) -> row[0..N) by lane 0
+template <int N>
+__device__ __forceinline__ void wave_reduce_to_row(double (&v)[N], bool use, double *row, int lane) {
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    double x = use ? v[j] : 0.0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    v[j] = x;
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) row[j] = v[j];
+  }
+}
+
 constexpr int NS = PCLMI_ICP_NSUMS;  // 24
 constexpr int ICP_WPB = 4;
 
 // One ICP iteration over the (Morton-ordered) source points.  See file header.
-__global__ __launch_bounds__(64 * ICP_WPB) void icp_step_kernel(TreeView t, float4 *__restrict__ pts, int n,
+// LANE: per-lane traversal (traverse.hpp lane_nearest) with `levels` rows of LDS per wave, started from the
+// distance to the previous step's neighbour (nn_slot, when have_prev) below the wave's common subtree;
+// !LANE: wave-uniform traversal (development switch PCLMI_NN1=union).
+template <bool LANE>
+__global__ __launch_bounds__(64 * ICP_WPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void icp_step_kernel(TreeView t, float4 *__restrict__ pts, int n,
                                                                  int apply, Xf T, float thr2f, double thr2,
-                                                                 const float4 *__restrict__ cloud,
-                                                                 int *__restrict__ nn_idx,
+                                                                 int *__restrict__ nn_idx, int *__restrict__ nn_slot,
                                                                  float *__restrict__ dist, double ox, double oy,
                                                                  double oz, double *__restrict__ partials,
-                                                                 const IcpDevState *__restrict__ st) {
+                                                                 const IcpDevState *__restrict__ st, int levels,
+                                                                 int have_prev) {
+  extern __shared__ float far_lds[];
   __shared__ double lds[ICP_WPB][NS];
   if (st) {  // device-resident loop: the pending transform and the stop flag live in device memory
     if (st->done) return;
@@ -120,12 +141,13 @@ __global__ __launch_bounds__(64 * ICP_WPB) void icp_step_kernel(TreeView t, floa
   const int blk = (blockIdx.x & 7) * per + (blockIdx.x >> 3);  // XCD-contiguous chunks (speed only)
   const int slot = (blk * ICP_WPB + wib) * 64 + lane;
   const bool wave_live = __builtin_amdgcn_readfirstlane(slot) < n;
-  double acc[NS];
-#pragma unroll
-  for (int j = 0; j < NS; ++j) acc[j] = 0.0;
+  const float4 *__restrict__ rows = reinterpret_cast<const float4 *>(t.slot);  // bucket order (x, y, z, idx bits)
+  bool paired = false, counted = false;
+  float4 p = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), 1.f);
+  float4 q = p;
+  float dc = 0.f, prev = 0.f;
   if (wave_live) {
     const bool alive = slot < n;
-    float4 p = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), 1.f);
     if (alive) {
       p = pts[slot];
       if (apply && finite3(p)) {
@@ -135,36 +157,64 @@ __global__ __launch_bounds__(64 * ICP_WPB) void icp_step_kernel(TreeView t, floa
     }
     const bool searchable = alive && finite3(p);
     if (!searchable) p.x = p.y = p.z = __builtin_nanf("");
-    const unsigned long long best = wave_nearest(t, p.x, p.y, p.z, searchable, lane);
+    unsigned long long best;
+    int bslot = 0;
+    if (LANE) {
+      float tau0 = __builtin_inff();
+      if (have_prev && searchable) {
+        const int j = nn_slot[slot];
+        if (j >= 0) {  // the previous neighbour is an indexed point: its distance bounds the new nearest one
+          const float4 o = rows[j];
+          tau0 = sq3(p.x - o.x, p.y - o.y, p.z - o.z);
+        }
+      }
+      const int root = have_prev ? wave_common_root(t, p.x, p.y, p.z, searchable, tau0) : 1;
+      best = lane_nearest(t, p.x, p.y, p.z, searchable, tau0,
+                          reinterpret_cast<float(*)[64]>(far_lds + (size_t)wib * levels * 64), lane, root, bslot);
+    } else {
+      best = wave_nearest(t, p.x, p.y, p.z, searchable, lane);
+    }
     if (alive) {
       const int idx = searchable ? (int)(unsigned int)(best & 0xffffffffull) : -1;
       const float d = searchable ? __uint_as_float((unsigned int)(best >> 32)) : __builtin_nanf("");
       nn_idx[slot] = idx;
+      if (LANE) nn_slot[slot] = searchable ? bslot : -1;
       if (searchable) {
-        const float dc = fminf(d, thr2f);  // icp.hpp:101
-        const float prev = dist[slot];
+        dc = fminf(d, thr2f);  // icp.hpp:101
+        prev = dist[slot];
         dist[slot] = dc;
-        acc[16] = (double)dc;
-        acc[17] = (double)dc - (double)prev;
-        acc[18] = 1.0;
-        acc[19] = ox;
-        acc[20] = oy;
-        acc[21] = oz;
+        counted = true;
         if ((double)d < thr2) {  // strict, icp.hpp:93
-          const float4 q = cloud[idx];
-          const double sx = (double)p.x - ox, sy = (double)p.y - oy, sz = (double)p.z - oz;
-          const double tx = (double)q.x - ox, ty = (double)q.y - oy, tz = (double)q.z - oz;
-          acc[0] = 1.0;
-          acc[1] = sx; acc[2] = sy; acc[3] = sz;
-          acc[4] = tx; acc[5] = ty; acc[6] = tz;
-          acc[7] = sx * tx; acc[8] = sx * ty; acc[9] = sx * tz;
-          acc[10] = sy * tx; acc[11] = sy * ty; acc[12] = sy * tz;
-          acc[13] = sz * tx; acc[14] = sz * ty; acc[15] = sz * tz;
+          q = LANE ? rows[bslot] : reinterpret_cast<const float4 *>(t.cloud)[idx];
+          paired = true;
         }
       }
     }
   }
-  block_reduce_store<NS, ICP_WPB>(acc, lds, lane, wib, partials + (size_t)blockIdx.x * NS);
+  // fp64 moments, reduced in three groups of eight so that at most 16 accumulator registers are live at a
+  // time (the register budget is 64 VGPRs = 8 waves per SIMD: the search is latency-bound)
+  const double sx = (double)p.x - ox, sy = (double)p.y - oy, sz = (double)p.z - oz;
+  const double tx = (double)q.x - ox, ty = (double)q.y - oy, tz = (double)q.z - oz;
+  const double one_p = paired ? 1.0 : 0.0, one_c = counted ? 1.0 : 0.0;
+  {
+    double v[8] = {one_p, sx, sy, sz, tx, ty, tz, sx * tx};
+    wave_reduce_to_row<8>(v, paired, &lds[wib][0], lane);
+  }
+  {
+    double v[8] = {sx * ty, sx * tz, sy * tx, sy * ty, sy * tz, sz * tx, sz * ty, sz * tz};
+    wave_reduce_to_row<8>(v, paired, &lds[wib][8], lane);
+  }
+  {
+    double v[8] = {(double)dc, (double)dc - (double)prev, one_c, ox, oy, oz, 0.0, 0.0};
+    wave_reduce_to_row<8>(v, counted, &lds[wib][16], lane);
+  }
+  __syncthreads();
+  if (threadIdx.x < NS) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < ICP_WPB; ++w) s += lds[w][threadIdx.x];
+    partials[(size_t)blockIdx.x * NS + threadIdx.x] = s;
+  }
 }
 
 // fixed-order sum of the block partials: block j of the grid produces out[j]
@@ -431,14 +481,21 @@ unsigned icp_step_blocks(size_t n) {
 }
 
 void launch_icp_step(const pclmi_tree *t, float4 *d_pts, size_t n, bool apply, const Xf &T, double thr2,
-                     int *d_nn, float *d_dist, const double origin[3], double *d_partials, double *d_sums,
-                     hipStream_t s, IcpDevState *st) {
+                     int *d_nn, int *d_nn_slot, float *d_dist, const double origin[3], double *d_partials,
+                     double *d_sums, hipStream_t s, IcpDevState *st, bool have_prev) {
   const unsigned blocks = icp_step_blocks(n);
+  const int levels = nn1_per_lane() ? lane_nearest_levels(t->M) : 0;
   {
     TimingScope ts(PCLMI_TIMER_ICP_STEP, s);
-    hipLaunchKernelGGL(icp_step_kernel, dim3(blocks), dim3(64 * ICP_WPB), 0, s, t->view(), d_pts, (int)n,
-                       apply ? 1 : 0, T, (float)thr2, thr2, (const float4 *)t->d_cloud, d_nn, d_dist, origin[0],
-                       origin[1], origin[2], d_partials, (const IcpDevState *)st);
+    if (levels > 0)
+      hipLaunchKernelGGL((icp_step_kernel<true>), dim3(blocks), dim3(64 * ICP_WPB),
+                         (size_t)ICP_WPB * levels * 64 * sizeof(float), s, t->view(), d_pts, (int)n, apply ? 1 : 0, T,
+                         (float)thr2, thr2, d_nn, d_nn_slot, d_dist, origin[0], origin[1], origin[2], d_partials,
+                         (const IcpDevState *)st, levels, have_prev ? 1 : 0);
+    else
+      hipLaunchKernelGGL((icp_step_kernel<false>), dim3(blocks), dim3(64 * ICP_WPB), 0, s, t->view(), d_pts, (int)n,
+                         apply ? 1 : 0, T, (float)thr2, thr2, d_nn, d_nn_slot, d_dist, origin[0], origin[1], origin[2],
+                         d_partials, (const IcpDevState *)st, 0, 0);
   }
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(NS), dim3(256), 0, s, d_partials, (int)blocks, NS, d_sums, st);
 }

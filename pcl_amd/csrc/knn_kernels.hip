@@ -241,6 +241,27 @@ __global__ __launch_bounds__(64 * WPB) void knn1_union_kernel(TreeView t, const 
   }
 }
 
+// K == 1, per-lane traversal (traverse.hpp lane_nearest): dynamic LDS = WPB x levels x 64 floats
+template <int WPB>
+__global__ __launch_bounds__(64 * WPB) void knn1_lane_kernel(TreeView t, const float *__restrict__ q,
+                                                              int q_stride_f, const int *__restrict__ order,
+                                                              int nq, int levels, int *__restrict__ out_idx,
+                                                              float *__restrict__ out_d2) {
+  extern __shared__ float far_lds[];
+  const int lane = threadIdx.x & 63;
+  LaneQuery lq;
+  if (!load_lane_query<WPB>(q, q_stride_f, order, nq, lq)) return;
+  int best_slot;
+  const unsigned long long best =
+      lane_nearest(t, lq.x, lq.y, lq.z, lq.searchable, __builtin_inff(),
+                   reinterpret_cast<float(*)[64]>(far_lds + (size_t)(threadIdx.x >> 6) * levels * 64), lane, 1,
+                   best_slot);
+  if (lq.alive) {
+    out_idx[lq.qi] = lq.searchable ? (int)(unsigned int)(best & 0xffffffffull) : -1;
+    out_d2[lq.qi] = lq.searchable ? __uint_as_float((unsigned int)(best >> 32)) : __builtin_nanf("");
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Any k: one query per lane, private traversal, (d2,index) max-heap in global scratch laid out
 // [k][nq] so that neighbouring lanes touch neighbouring words.  Slow path for k > 32.
@@ -461,8 +482,14 @@ int launch_knn(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, s
     constexpr int WPB = 4;
     unsigned waves = (unsigned)((nq + 63) / 64);
     unsigned blocks = ((waves + WPB - 1) / WPB + 7) & ~7u;
-    hipLaunchKernelGGL((knn1_union_kernel<WPB>), dim3(blocks), dim3(64 * WPB), 0, s, t->view(), d_q, (int)qsf,
-                       order, (int)nq, d_idx, d_d2);
+    if (nn1_per_lane()) {
+      const int levels = lane_nearest_levels(t->M);
+      hipLaunchKernelGGL((knn1_lane_kernel<WPB>), dim3(blocks), dim3(64 * WPB), (size_t)WPB * levels * 64 * sizeof(float),
+                         s, t->view(), d_q, (int)qsf, order, (int)nq, levels, d_idx, d_d2);
+    } else {
+      hipLaunchKernelGGL((knn1_union_kernel<WPB>), dim3(blocks), dim3(64 * WPB), 0, s, t->view(), d_q, (int)qsf,
+                         order, (int)nq, d_idx, d_d2);
+    }
   } else if (k_eff <= 2) {
     launch_union_ix<2, 16, 1>(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
   } else if (k_eff <= 4) {

@@ -202,8 +202,11 @@ void launch_unpermute(const float4 *in, const int *order, size_t n, float4 *out,
 unsigned icp_step_blocks(size_t n);
 // st (nullable): take the pending transform from the device-side state instead of apply / T
 void launch_icp_step(const pclmi_tree *t, float4 *d_pts, size_t n, bool apply, const Xf &T, double thr2,
-                     int *d_nn, float *d_dist, const double origin[3], double *d_partials, double *d_sums,
-                     hipStream_t s, IcpDevState *st = nullptr);
+                     int *d_nn, int *d_nn_slot, float *d_dist, const double origin[3], double *d_partials,
+                     double *d_sums, hipStream_t s, IcpDevState *st = nullptr, bool have_prev = false);
+// development switch (environment PCLMI_NN1=union): 1-NN searches use the wave-uniform traversal instead of
+// the per-lane one
+bool nn1_per_lane();
 unsigned pair_reduce_blocks(size_t n);
 void launch_pair_reduce(const float4 *src, const int *sidx, const float4 *tgt, const int *tidx,
                         const unsigned char *flags, size_t n, const double origin[3], double *d_partials,

@@ -257,6 +257,121 @@ __device__ __forceinline__ unsigned long long wave_nearest(const TreeView &t, fl
   return best;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Per-lane exact 1-NN: every lane walks the tree for its OWN query - near child first, the far
+// child's box distance remembered per level in LDS (far[level][lane]), stackless backtracking through
+// the implicit heap order (parent = id >> 1, sibling = id ^ 1, one "second child taken" bit per level).
+// With a good starting bound (ICP: the distance to the previous iteration's neighbour) a lane touches
+// one root-to-leaf path and a leaf or two, ~4x fewer VALU instructions than the wave-uniform walk
+// above; neighbouring lanes follow neighbouring paths, so the vector loads hit the same L1/L2 lines.
+// tau0: any upper bound of the lane's nearest distance that is attained by an indexed point (+inf when
+// none is known).  far: this wave's LDS scratch with lane_nearest_levels(M) rows.  Returns the best
+// 64-bit key (d2 bits << 32 | index); lanes with searchable == false return (FLT_MAX, 0x7fffffff).
+__host__ __device__ inline int lane_nearest_levels(int M) {
+  int lv = 1;
+  while ((1ll << lv) < 2ll * (long long)(M > 0 ? M : 1)) ++lv;
+  return lv + 1;
+}
+
+// Wave-uniform prefix of lane_nearest: walks down from the root while only ONE child box is within the
+// bound of any lane (boxes through scalar loads), and returns the node the per-lane walks can start at -
+// with tight bounds (ICP after the first iteration) that is most of the way down, so the lanes only
+// diverge over the last few levels.  Lanes with an infinite bound need every box: the walk stays at 1.
+__device__ __forceinline__ int wave_common_root(const TreeView &t, float qx, float qy, float qz, bool active,
+                                                float tau) {
+  const cgrp_ptr box2 = (cgrp_ptr)t.box;
+  const int M = t.M;
+  int root = 1;
+  while (root < M) {
+    const f16v b = box2[root];
+    const float m0 = box_dist(qx, qy, qz, b[0], b[1], b[2], b[3], b[4], b[5]);
+    const float m1 = box_dist(qx, qy, qz, b[8], b[9], b[10], b[11], b[12], b[13]);
+    const bool n0 = __any(active && m0 <= tau), n1 = __any(active && m1 <= tau);
+    if (n0 == n1) break;  // both needed (or neither: nothing left to find below)
+    root = 2 * root + (n1 ? 1 : 0);
+  }
+  return root;
+}
+
+__device__ __forceinline__ unsigned long long lane_nearest(const TreeView &t, float qx, float qy, float qz,
+                                                           bool searchable, float tau0, float (*far)[64], int lane,
+                                                           int root, int &best_slot) {
+  // root: node the walk starts (and ends) at - 1, or wave_common_root(); best_slot: bucket slot of the result
+  unsigned long long best = make_key(3.402823466e+38f, 0x7fffffff);
+  best_slot = 0;
+  float tau = tau0;
+  const int M = t.M;
+  int node = root;
+  unsigned int trail = 0;  // bit l set: the node on the current path at level l is the second child visited
+  bool active = searchable;
+  while (__any(active)) {
+    // ---- descend towards the nearer child while the subtree can still hold something <= tau
+    bool pruned = false;
+    while (__any(active && !pruned && node < M)) {
+      if (active && !pruned && node < M) {
+        const float4 *b = reinterpret_cast<const float4 *>(t.box + (size_t)node * 16);
+        const float4 b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
+        const float m0 = box_dist(qx, qy, qz, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y);
+        const float m1 = box_dist(qx, qy, qz, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y);
+        const bool right = m1 < m0;
+        const float mn = right ? m1 : m0, mf = right ? m0 : m1;
+        if (mn <= tau) {
+          node = 2 * node + (right ? 1 : 0);
+          const int lvl = 31 - __clz(node);
+          far[lvl][lane] = mf;
+          trail &= ~(1u << lvl);
+        } else {
+          pruned = true;
+        }
+      }
+    }
+    // ---- leaf bucket: all 16 slots (padded slots are at distance +inf)
+    if (active && !pruned) {
+      const float4 *rec = reinterpret_cast<const float4 *>(t.leaf + (size_t)(node - M) * (4 * L));
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const float4 X = rec[g * 4 + 0], Y = rec[g * 4 + 1], Z = rec[g * 4 + 2], I = rec[g * 4 + 3];
+        const unsigned long long k0 = make_key(sq3(qx - X.x, qy - Y.x, qz - Z.x), __float_as_int(I.x));
+        const unsigned long long k1 = make_key(sq3(qx - X.y, qy - Y.y, qz - Z.y), __float_as_int(I.y));
+        const unsigned long long k2 = make_key(sq3(qx - X.z, qy - Y.z, qz - Z.z), __float_as_int(I.z));
+        const unsigned long long k3 = make_key(sq3(qx - X.w, qy - Y.w, qz - Z.w), __float_as_int(I.w));
+        const bool a1 = k1 < k0, b1 = k3 < k2;
+        const unsigned long long ka = a1 ? k1 : k0, kb = b1 ? k3 : k2;
+        const int pa = a1 ? 1 : 0, pb = b1 ? 3 : 2;
+        const bool c1 = kb < ka;
+        const unsigned long long kc = c1 ? kb : ka;
+        const int pc = c1 ? pb : pa;
+        if (kc < best) {
+          best = kc;
+          best_slot = (node - M) * L + g * 4 + pc;
+        }
+      }
+      tau = fminf(tau, __uint_as_float((unsigned int)(best >> 32)));
+    }
+    // ---- back up to the deepest level whose far child is still within tau (non-strict: an equal
+    //      distance with a lower index may hide there)
+    if (active) {
+      for (;;) {
+        if (node == root) {
+          active = false;
+          break;
+        }
+        const int lvl = 31 - __clz(node);
+        const unsigned int bit = 1u << lvl;
+        if (!(trail & bit)) {
+          trail |= bit;
+          if (far[lvl][lane] <= tau) {
+            node ^= 1;
+            break;
+          }
+        }
+        node >>= 1;
+      }
+    }
+  }
+  return best;
+}
+
 }  // namespace dev
 }  // namespace pclmi
 #endif
