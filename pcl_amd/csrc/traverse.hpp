@@ -283,9 +283,28 @@ __device__ __forceinline__ int wave_common_root(const TreeView &t, float qx, flo
   const int M = t.M;
   int root = 1;
   while (root < M) {
+    const f2v q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
+    if (2 * root + 1 < M) {
+      // two levels per step: the four grandchildren boxes are two adjacent 64-byte lines
+      const f16v ba = box2[2 * root], bb = box2[2 * root + 1];
+      const f2v m01 = box_dist_pk(q2x, q2y, q2z, f2v{ba[0], ba[8]}, f2v{ba[1], ba[9]}, f2v{ba[2], ba[10]},
+                                  f2v{ba[3], ba[11]}, f2v{ba[4], ba[12]}, f2v{ba[5], ba[13]});
+      const f2v m23 = box_dist_pk(q2x, q2y, q2z, f2v{bb[0], bb[8]}, f2v{bb[1], bb[9]}, f2v{bb[2], bb[10]},
+                                  f2v{bb[3], bb[11]}, f2v{bb[4], bb[12]}, f2v{bb[5], bb[13]});
+      const bool n0 = __any(active && m01.x <= tau), n1 = __any(active && m01.y <= tau);
+      const bool n2 = __any(active && m23.x <= tau), n3 = __any(active && m23.y <= tau);
+      const int cnt = (int)n0 + (int)n1 + (int)n2 + (int)n3;
+      if (cnt == 1) {
+        root = 4 * root + (n1 ? 1 : n2 ? 2 : n3 ? 3 : 0);
+        continue;
+      }
+      if (cnt == 2 && n0 == n1) root = 2 * root + (n2 ? 1 : 0);  // both inside one child: that child, and stop
+      break;
+    }
     const f16v b = box2[root];
-    const float m0 = box_dist(qx, qy, qz, b[0], b[1], b[2], b[3], b[4], b[5]);
-    const float m1 = box_dist(qx, qy, qz, b[8], b[9], b[10], b[11], b[12], b[13]);
+    const f2v m01 = box_dist_pk(q2x, q2y, q2z, f2v{b[0], b[8]}, f2v{b[1], b[9]}, f2v{b[2], b[10]},
+                                f2v{b[3], b[11]}, f2v{b[4], b[12]}, f2v{b[5], b[13]});
+    const float m0 = m01.x, m1 = m01.y;
     const bool n0 = __any(active && m0 <= tau), n1 = __any(active && m1 <= tau);
     if (n0 == n1) break;  // both needed (or neither: nothing left to find below)
     root = 2 * root + (n1 ? 1 : 0);
@@ -304,24 +323,52 @@ __device__ __forceinline__ unsigned long long lane_nearest(const TreeView &t, fl
   int node = root;
   unsigned int trail = 0;  // bit l set: the node on the current path at level l is the second child visited
   bool active = searchable;
+  const f2v q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
   while (__any(active)) {
     // ---- descend towards the nearer child while the subtree can still hold something <= tau
     bool pruned = false;
     while (__any(active && !pruned && node < M)) {
       if (active && !pruned && node < M) {
-        const float4 *b = reinterpret_cast<const float4 *>(t.box + (size_t)node * 16);
-        const float4 b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
-        const float m0 = box_dist(qx, qy, qz, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y);
-        const float m1 = box_dist(qx, qy, qz, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y);
-        const bool right = m1 < m0;
-        const float mn = right ? m1 : m0, mf = right ? m0 : m1;
-        if (mn <= tau) {
-          node = 2 * node + (right ? 1 : 0);
-          const int lvl = 31 - __clz(node);
-          far[lvl][lane] = mf;
-          trail &= ~(1u << lvl);
+        if (2 * node + 1 < M) {
+          // two levels per step (half as many dependent loads): the four grandchildren boxes; a child's
+          // bound is the smaller of its two children's box distances
+          const float4 *b = reinterpret_cast<const float4 *>(t.box + (size_t)node * 32);
+          const float4 a0 = b[0], a1 = b[1], a2 = b[2], a3 = b[3], c0 = b[4], c1 = b[5], c2 = b[6], c3 = b[7];
+          const f2v m01 = box_dist_pk(q2x, q2y, q2z, f2v{a0.x, a2.x}, f2v{a0.y, a2.y}, f2v{a0.z, a2.z},
+                                      f2v{a0.w, a2.w}, f2v{a1.x, a3.x}, f2v{a1.y, a3.y});
+          const f2v m23 = box_dist_pk(q2x, q2y, q2z, f2v{c0.x, c2.x}, f2v{c0.y, c2.y}, f2v{c0.z, c2.z},
+                                      f2v{c0.w, c2.w}, f2v{c1.x, c3.x}, f2v{c1.y, c3.y});
+          const float lo01 = fminf(m01.x, m01.y), lo23 = fminf(m23.x, m23.y);
+          const bool right = lo23 < lo01;                     // which child
+          const float g0 = right ? m23.x : m01.x, g1 = right ? m23.y : m01.y;
+          const bool gright = g1 < g0;                        // which grandchild inside it
+          const float mn = gright ? g1 : g0;
+          if (mn <= tau) {
+            const int child = 2 * node + (right ? 1 : 0);
+            node = 2 * child + (gright ? 1 : 0);
+            const int lvl = 31 - __clz(node);
+            far[lvl - 1][lane] = right ? lo01 : lo23;
+            far[lvl][lane] = gright ? g0 : g1;
+            trail &= ~(3u << (lvl - 1));
+          } else {
+            pruned = true;
+          }
         } else {
-          pruned = true;
+          const float4 *b = reinterpret_cast<const float4 *>(t.box + (size_t)node * 16);
+          const float4 b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
+          const f2v m01 = box_dist_pk(q2x, q2y, q2z, f2v{b0.x, b2.x}, f2v{b0.y, b2.y}, f2v{b0.z, b2.z},
+                                      f2v{b0.w, b2.w}, f2v{b1.x, b3.x}, f2v{b1.y, b3.y});
+          const float m0 = m01.x, m1 = m01.y;
+          const bool right = m1 < m0;
+          const float mn = right ? m1 : m0, mf = right ? m0 : m1;
+          if (mn <= tau) {
+            node = 2 * node + (right ? 1 : 0);
+            const int lvl = 31 - __clz(node);
+            far[lvl][lane] = mf;
+            trail &= ~(1u << lvl);
+          } else {
+            pruned = true;
+          }
         }
       }
     }
@@ -331,10 +378,12 @@ __device__ __forceinline__ unsigned long long lane_nearest(const TreeView &t, fl
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         const float4 X = rec[g * 4 + 0], Y = rec[g * 4 + 1], Z = rec[g * 4 + 2], I = rec[g * 4 + 3];
-        const unsigned long long k0 = make_key(sq3(qx - X.x, qy - Y.x, qz - Z.x), __float_as_int(I.x));
-        const unsigned long long k1 = make_key(sq3(qx - X.y, qy - Y.y, qz - Z.y), __float_as_int(I.y));
-        const unsigned long long k2 = make_key(sq3(qx - X.z, qy - Y.z, qz - Z.z), __float_as_int(I.z));
-        const unsigned long long k3 = make_key(sq3(qx - X.w, qy - Y.w, qz - Z.w), __float_as_int(I.w));
+        const f2v d01 = sq3_pk(q2x - f2v{X.x, X.y}, q2y - f2v{Y.x, Y.y}, q2z - f2v{Z.x, Z.y});
+        const f2v d23 = sq3_pk(q2x - f2v{X.z, X.w}, q2y - f2v{Y.z, Y.w}, q2z - f2v{Z.z, Z.w});
+        const unsigned long long k0 = make_key(d01.x, __float_as_int(I.x));
+        const unsigned long long k1 = make_key(d01.y, __float_as_int(I.y));
+        const unsigned long long k2 = make_key(d23.x, __float_as_int(I.z));
+        const unsigned long long k3 = make_key(d23.y, __float_as_int(I.w));
         const bool a1 = k1 < k0, b1 = k3 < k2;
         const unsigned long long ka = a1 ? k1 : k0, kb = b1 ? k3 : k2;
         const int pa = a1 ? 1 : 0, pb = b1 ? 3 : 2;
