@@ -105,10 +105,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal of the N > 1 path on a one-GPU box (never used by the driver): every rank on device 0,
+    # collectives over gloo instead of RCCL (RCCL refuses two ranks on one GPU).
+    rehearsal = os.environ.get("PCLMI_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     if world != args.gpus and rank == 0:
         print("bench.py: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available() or capi.device_count() == 0:
@@ -116,6 +124,12 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     capi.load_library().pclmi_set_device(local)
+
+    verbose = rehearsal or os.environ.get("PCLMI_BENCH_VERBOSE") == "1"
+
+    def log(msg):
+        if verbose:
+            print("[bench rank %d] %s" % (rank, msg), file=sys.stderr, flush=True)
 
     def barrier():
         torch.cuda.synchronize()
@@ -131,6 +145,7 @@ def main():
         return float(t.item())
 
     # ---- kNN headline -------------------------------------------------------------------------
+    log("process group up (world %d), building the target tree" % world)
     target = uniform_cloud(N_TARGET, SEED_T, 0, 1024)
     t0 = time.time()
     tree = capi.Tree(target)  # replicated on every GPU
@@ -148,6 +163,7 @@ def main():
     def step():
         tree.knn_dev(q.data_ptr(), N_QUERY, 16, K, idx.data_ptr(), d2.data_ptr(), stream)
 
+    log("tree built in %.2f s, warm-up" % build_s)
     for _ in range(args.warmup):
         step()
     capi.timing_enable(True)
@@ -158,6 +174,7 @@ def main():
     for _ in range(args.steps):
         step()
     barrier()
+    log("timed region done")
     elapsed = max_over_ranks(time.perf_counter() - t0)
     k_ms, k_n = capi.timing_read(capi.TIMER_KNN, reset=True)
     o_ms, o_n = capi.timing_read(capi.TIMER_ORDER, reset=True)
@@ -204,7 +221,8 @@ def main():
 
     # ---- ICP iterations / s (configs[3]) -------------------------------------------------------
     if not args.no_icp:
-        out["icp"] = bench_icp(args, capi, torch, dist, world, rank, dev, barrier, max_over_ranks)
+        log("kNN done: %.3e queries/s; ICP next" % value)
+        out["icp"] = bench_icp(args, capi, torch, dist, world, rank, dev, barrier, max_over_ranks, log)
 
     # ---- CPU baseline (rank 0, N = 1 only) -----------------------------------------------------
     if world == 1 and not args.no_cpu:
@@ -216,7 +234,7 @@ def main():
         dist.destroy_process_group()
 
 
-def bench_icp(args, capi, torch, dist, world, rank, dev, barrier, max_over_ranks):
+def bench_icp(args, capi, torch, dist, world, rank, dev, barrier, max_over_ranks, log=lambda m: None):
     n = 1_000_000
     tgt = surface_cloud(n, SEED_T + 10)
     # rigid motion to recover: 1 degree about (1,1,1) through the cloud centre + (2,-1,0.5)
@@ -255,7 +273,9 @@ def bench_icp(args, capi, torch, dist, world, rank, dev, barrier, max_over_ranks
         ctx.end(want_aligned=False)
         return dt, T_final, st.last_correspondences
 
+    log("ICP clouds and tree ready, warm-up align")
     run()  # warm-up pass (allocations, first-touch, RCCL channel set-up)
+    log("ICP warm-up done, timed align")
     capi.timing_enable(True)
     capi.timing_read(capi.TIMER_ICP_STEP, reset=True)
     dt, T_final, npairs = run()

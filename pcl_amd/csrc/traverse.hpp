@@ -312,13 +312,13 @@ __device__ __forceinline__ int wave_common_root(const TreeView &t, float qx, flo
   return root;
 }
 
-__device__ __forceinline__ unsigned long long lane_nearest(const TreeView &t, float qx, float qy, float qz,
-                                                           bool searchable, float tau0, float (*far)[64], int lane,
-                                                           int root, int &best_slot) {
-  // root: node the walk starts (and ends) at - 1, or wave_common_root(); best_slot: bucket slot of the result
-  unsigned long long best = make_key(3.402823466e+38f, 0x7fffffff);
-  best_slot = 0;
-  float tau = tau0;
+// The walk itself, shared by the 1-NN and the k-NN kernels.  leaf(leaf_number, tau) scans one bucket for
+// the calling lane and returns the lane's new bound (<= tau); round() runs once per outer round with the
+// whole wave converged (the k-NN kernel compacts its candidate buffer there).
+template <class LeafFn, class RoundFn>
+__device__ __forceinline__ void lane_traverse(const TreeView &t, float qx, float qy, float qz, bool searchable,
+                                              float tau, float (*far)[64], int lane, int root, LeafFn leaf,
+                                              RoundFn round) {
   const int M = t.M;
   int node = root;
   unsigned int trail = 0;  // bit l set: the node on the current path at level l is the second child visited
@@ -372,31 +372,9 @@ __device__ __forceinline__ unsigned long long lane_nearest(const TreeView &t, fl
         }
       }
     }
-    // ---- leaf bucket: all 16 slots (padded slots are at distance +inf)
-    if (active && !pruned) {
-      const float4 *rec = reinterpret_cast<const float4 *>(t.leaf + (size_t)(node - M) * (4 * L));
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const float4 X = rec[g * 4 + 0], Y = rec[g * 4 + 1], Z = rec[g * 4 + 2], I = rec[g * 4 + 3];
-        const f2v d01 = sq3_pk(q2x - f2v{X.x, X.y}, q2y - f2v{Y.x, Y.y}, q2z - f2v{Z.x, Z.y});
-        const f2v d23 = sq3_pk(q2x - f2v{X.z, X.w}, q2y - f2v{Y.z, Y.w}, q2z - f2v{Z.z, Z.w});
-        const unsigned long long k0 = make_key(d01.x, __float_as_int(I.x));
-        const unsigned long long k1 = make_key(d01.y, __float_as_int(I.y));
-        const unsigned long long k2 = make_key(d23.x, __float_as_int(I.z));
-        const unsigned long long k3 = make_key(d23.y, __float_as_int(I.w));
-        const bool a1 = k1 < k0, b1 = k3 < k2;
-        const unsigned long long ka = a1 ? k1 : k0, kb = b1 ? k3 : k2;
-        const int pa = a1 ? 1 : 0, pb = b1 ? 3 : 2;
-        const bool c1 = kb < ka;
-        const unsigned long long kc = c1 ? kb : ka;
-        const int pc = c1 ? pb : pa;
-        if (kc < best) {
-          best = kc;
-          best_slot = (node - M) * L + g * 4 + pc;
-        }
-      }
-      tau = fminf(tau, __uint_as_float((unsigned int)(best >> 32)));
-    }
+    // ---- leaf bucket
+    if (active && !pruned) tau = leaf(node - M, tau);
+    round();
     // ---- back up to the deepest level whose far child is still within tau (non-strict: an equal
     //      distance with a lower index may hide there)
     if (active) {
@@ -418,6 +396,43 @@ __device__ __forceinline__ unsigned long long lane_nearest(const TreeView &t, fl
       }
     }
   }
+}
+
+__device__ __forceinline__ unsigned long long lane_nearest(const TreeView &t, float qx, float qy, float qz,
+                                                           bool searchable, float tau0, float (*far)[64], int lane,
+                                                           int root, int &best_slot) {
+  // root: node the walk starts (and ends) at - 1, or wave_common_root(); best_slot: bucket slot of the result
+  unsigned long long best = make_key(3.402823466e+38f, 0x7fffffff);
+  int bslot = 0;
+  const f2v q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
+  lane_traverse(
+      t, qx, qy, qz, searchable, tau0, far, lane, root,
+      [&](int leafno, float tau) {  // all 16 slots (padded slots are at distance +inf)
+        const float4 *rec = reinterpret_cast<const float4 *>(t.leaf + (size_t)leafno * (4 * L));
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const float4 X = rec[g * 4 + 0], Y = rec[g * 4 + 1], Z = rec[g * 4 + 2], I = rec[g * 4 + 3];
+          const f2v d01 = sq3_pk(q2x - f2v{X.x, X.y}, q2y - f2v{Y.x, Y.y}, q2z - f2v{Z.x, Z.y});
+          const f2v d23 = sq3_pk(q2x - f2v{X.z, X.w}, q2y - f2v{Y.z, Y.w}, q2z - f2v{Z.z, Z.w});
+          const unsigned long long k0 = make_key(d01.x, __float_as_int(I.x));
+          const unsigned long long k1 = make_key(d01.y, __float_as_int(I.y));
+          const unsigned long long k2 = make_key(d23.x, __float_as_int(I.z));
+          const unsigned long long k3 = make_key(d23.y, __float_as_int(I.w));
+          const bool a1 = k1 < k0, b1 = k3 < k2;
+          const unsigned long long ka = a1 ? k1 : k0, kb = b1 ? k3 : k2;
+          const int pa = a1 ? 1 : 0, pb = b1 ? 3 : 2;
+          const bool c1 = kb < ka;
+          const unsigned long long kc = c1 ? kb : ka;
+          const int pc = c1 ? pb : pa;
+          if (kc < best) {
+            best = kc;
+            bslot = leafno * L + g * 4 + pc;
+          }
+        }
+        return fminf(tau, __uint_as_float((unsigned int)(best >> 32)));
+      },
+      [] {});
+  best_slot = bslot;
   return best;
 }
 
