@@ -1,0 +1,66 @@
+// test_pcd_io.cpp - host-only check of include/pcl/io/pcd_io.h: the ASCII v.5 fixture loads, binary and
+// ASCII files written by the facade read back bit-identically, extra fields are skipped, NaN rows survive.
+// usage: test_pcd_io <tests/golden dir> <scratch dir>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <string>
+
+#include <pcl/io/pcd_io.h>
+#include <pcl/point_types.h>
+
+static int g_fail = 0;
+#define EXPECT(c) do { if (!(c)) { ++g_fail; std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); } } while (0)
+
+static bool same(const pcl::PointCloud<pcl::PointXYZ> &a, const pcl::PointCloud<pcl::PointXYZ> &b) {
+  if (a.size() != b.size() || a.width != b.width || a.height != b.height) return false;
+  for (size_t i = 0; i < a.size(); ++i)
+    if (std::memcmp(a.points[i].data, b.points[i].data, 12) != 0) return false;
+  return true;
+}
+
+int main(int argc, char **argv) {
+  if (argc < 3) return 2;
+  const std::string dir = argv[1], tmp = argv[2];
+  pcl::PointCloud<pcl::PointXYZ> bun, back;
+  EXPECT(pcl::io::loadPCDFile(dir + "/bun0.pcd", bun) == 0);
+  EXPECT(bun.size() == 397 && bun.width == 397 && bun.height == 1 && bun.is_dense);
+  EXPECT(bun.points[0].x == 0.0054216f && bun.points[0].y == 0.11349f && bun.points[0].z == 0.040749f);
+  EXPECT(bun.points[396].data[3] == 1.f);
+  EXPECT(pcl::io::savePCDFileBinary(tmp + "/b.pcd", bun) == 0);
+  EXPECT(pcl::io::loadPCDFile(tmp + "/b.pcd", back) == 0 && same(bun, back));
+  EXPECT(pcl::io::savePCDFile(tmp + "/a.pcd", bun) == 0);  // ASCII, 8 significant digits: exact for these inputs
+  EXPECT(pcl::io::loadPCDFile(tmp + "/a.pcd", back) == 0 && same(bun, back));
+  // the written header is the reference's v0.7 layout (impl/pcd_io.hpp:72-121)
+  {
+    std::ifstream f(tmp + "/b.pcd", std::ios::binary);
+    std::string l1, l2, l3;
+    std::getline(f, l1); std::getline(f, l2); std::getline(f, l3);
+    EXPECT(l1 == "# .PCD v0.7 - Point Cloud Data file format" && l2 == "VERSION 0.7" && l3 == "FIELDS x y z");
+  }
+  // extra fields and a different order are skipped / mapped by name; NaN rows make the cloud non-dense
+  {
+    std::ofstream f(tmp + "/c.pcd");
+    f << "VERSION .7\nFIELDS intensity z y x rgb\nSIZE 4 4 4 4 4\nTYPE F F F F U\nCOUNT 1 1 1 1 1\nWIDTH 2\nHEIGHT 2\n"
+         "VIEWPOINT 0 0 0 1 0 0 0\nPOINTS 4\nDATA ascii\n9 3 2 1 255\n9 6 5 4 0\n9 nan nan nan 0\n9 -1.5 2.5e-3 1e3 7\n";
+  }
+  pcl::PointCloud<pcl::PointXYZ> c;
+  EXPECT(pcl::io::loadPCDFile(tmp + "/c.pcd", c) == 0);
+  EXPECT(c.size() == 4 && c.width == 2 && c.height == 2 && !c.is_dense);
+  EXPECT(c.points[0].x == 1.f && c.points[0].y == 2.f && c.points[0].z == 3.f);
+  EXPECT(std::isnan(c.points[2].x) && c.points[3].x == 1e3f && c.points[3].y == 2.5e-3f && c.points[3].z == -1.5f);
+  EXPECT(pcl::io::savePCDFileBinary(tmp + "/d.pcd", c) == 0 && pcl::io::loadPCDFile(tmp + "/d.pcd", back) == 0);
+  EXPECT(same(c, back) && !back.is_dense);
+  // errors: missing file, unsupported encoding, empty cloud
+  pcl::console::setVerbosityLevel(pcl::console::L_ALWAYS);
+  EXPECT(pcl::io::loadPCDFile(tmp + "/missing.pcd", back) == -1);
+  {
+    std::ofstream f(tmp + "/e.pcd");
+    f << "VERSION .7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\nWIDTH 1\nHEIGHT 1\nPOINTS 1\nDATA binary_compressed\n";
+  }
+  EXPECT(pcl::io::loadPCDFile(tmp + "/e.pcd", back) == -1);
+  EXPECT(pcl::io::savePCDFile(tmp + "/f.pcd", pcl::PointCloud<pcl::PointXYZ>()) == -1);
+  std::printf(g_fail ? "test_pcd_io: %d FAILED\n" : "test_pcd_io: all checks passed\n", g_fail);
+  return g_fail ? 1 : 0;
+}
