@@ -167,3 +167,35 @@ def test_partial_wave_and_nan_queries_do_not_walk_the_whole_tree(capi, orc):
         assert np.array_equal(gi[good], oi) and np.array_equal(gd[good], od)
         assert (gi[~good] == -1).all() and np.isnan(gd[~good]).all()
         assert dt < 0.05, "k=%d took %.1f ms" % (k, dt * 1e3)
+
+
+def test_concurrent_const_queries_on_one_tree(capi, orc):
+    """The reference's const search methods are called concurrently from OpenMP loops on one tree
+    (features/.../impl/normal_3d_omp.hpp:62-68, test/test_search.cpp:308-325); every call taking a
+    const pclmi_tree* must be re-entrant.  ctypes releases the GIL, so these threads really overlap."""
+    import threading
+    pts = util.uniform_cloud(200_000, 77, 0, 100)
+    t = capi.Tree(pts)
+    qs = [util.uniform_cloud(3000 + 137 * i, 100 + i, 0, 100) for i in range(8)]
+    serial = [(t.knn(q, 16), t.knn(q, 1), t.radius(q, 1.5)) for q in qs]
+    got, errs = [None] * len(qs), []
+
+    def work(i):
+        try:
+            for _ in range(3):
+                got[i] = (t.knn(qs[i], 16), t.knn(qs[i], 1), t.radius(qs[i], 1.5))
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(qs))]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errs, errs
+    for s, g in zip(serial, got):
+        for a, b in zip(s, g):
+            for u, v in zip(a, b):
+                assert np.array_equal(u, v, equal_nan=True)
+    oi, od = orc.Tree(pts).knn(qs[0], 16, nthreads=8)
+    assert np.array_equal(got[0][0][0], oi)
