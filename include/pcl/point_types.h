@@ -53,6 +53,25 @@ struct PointNormal {
   PointNormal() : data{0.f, 0.f, 0.f, 1.f}, data_n{0.f, 0.f, 0.f, 0.f}, data_c{0.f, 0.f, 0.f, 0.f} {}
 };
 
+// common/include/pcl/impl/point_types.hpp: Normal = normal[3] (+pad) and curvature (+pad), 32 bytes
+struct Normal {
+  union alignas(16) {
+    float data_n[4];
+    float normal[3];
+    struct {
+      float normal_x, normal_y, normal_z;
+    };
+  };
+  union alignas(16) {
+    float data_c[4];
+    struct {
+      float curvature;
+    };
+  };
+  Normal() : data_n{0.f, 0.f, 0.f, 0.f}, data_c{0.f, 0.f, 0.f, 0.f} {}
+  Normal(float nx, float ny, float nz) : data_n{nx, ny, nz, 0.f}, data_c{0.f, 0.f, 0.f, 0.f} {}
+};
+
 inline std::ostream &operator<<(std::ostream &os, const PointXYZ &p) {
   return os << "(" << p.x << "," << p.y << "," << p.z << ")";
 }

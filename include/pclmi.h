@@ -289,6 +289,34 @@ int pclmi_icp_run_dev(pclmi_icp_ctx *ctx, double max_correspondence_distance, in
                       void *stream);
 int pclmi_icp_state(pclmi_icp_ctx *ctx, float final_T[16], pclmi_icp_stats *stats);
 
+/* Surface normals ----------------------------------------------------------------------
+ * The largest caller of the batched searches.  Replaces
+ * pcl::NormalEstimation<PointInT, PointOutT>::computeFeature
+ * (features/include/pcl/features/impl/normal_3d.hpp:46-98) together with the per-point search of
+ * Feature::compute (features/include/pcl/features/impl/feature.hpp:143-159,188-220): for every
+ * query the k nearest (k > 0, setKSearch) or all points within radius (radius > 0,
+ * setRadiusSearch) of the surface tree - exactly one of the two -, the least-squares plane through
+ * them (computeMeanAndCovarianceMatrix + solvePlaneParameters, centroid.hpp:553-617,
+ * feature.hpp:47-86), curvature = |lambda0 / (lambda0 + lambda1 + lambda2)|, normal flipped towards
+ * the viewpoint (flipNormalTowardsViewpoint, normal_3d.h:162-181; NULL = origin).
+ * normals holds nq x 4 floats (nx, ny, nz, curvature) - the layout of pcl::Normal's data_n[0..2] and
+ * curvature.  Rows of non-finite queries or without neighbours are NaN (normal_3d.hpp:62-68).
+ * Moments are accumulated in fp64 about the query point and the eigenproblem is solved in fp64:
+ * at least as accurate as the reference's fp32 (which loses the covariance of clouds far from the
+ * origin).  With fewer than 3 non-collinear neighbours the plane is not unique and the result is
+ * one valid solution, not necessarily the reference's. */
+int pclmi_normals(const pclmi_tree *surface, const float *queries, size_t nq, size_t q_stride_bytes,
+                  int k, double radius, const float viewpoint[3], float *normals);
+int pclmi_normals_dev(const pclmi_tree *surface, const float *d_queries, size_t nq,
+                      size_t q_stride_bytes, int k, double radius, const float viewpoint[3],
+                      float *d_normals, void *stream);
+/* pcl::computePointNormal on one index list (features/include/pcl/features/normal_3d.h:58-104):
+ * plane = (nx, ny, nz, d), d = -n . centroid; indices NULL = the whole cloud.  The sign of the
+ * normal is not defined by the reference's solver either; flip it towards a viewpoint if needed.
+ * Host computation (one list is O(n)); needs no GPU. */
+int pclmi_point_normal(const float *pts, size_t n_rows, size_t stride_bytes, const int32_t *indices,
+                       size_t n_indices, float plane[4], float *curvature);
+
 #ifdef __cplusplus
 }
 #endif

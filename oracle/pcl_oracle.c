@@ -1189,3 +1189,171 @@ double orc_fitness_score(const float *src, int64_t ns, int ss, const float *tgt,
   orc_tree_free(tree);
   return nr > 0 ? score / (double)nr : DBL_MAX;
 }
+
+/* ===========================================================================================
+ * Surface normals (features/include/pcl/features/normal_3d.h, impl/normal_3d.hpp)
+ * =========================================================================================== */
+
+/* computeRoots2 (common/include/pcl/common/eigen.h:105-116) */
+static void eig_roots2(float b, float c, float roots[3]) {
+  roots[0] = 0.f;
+  float d = (float)(b * b - 4.0 * c);
+  if (d < 0.0) d = 0.0f;
+  float sd = sqrtf(d);
+  roots[2] = 0.5f * (b + sd);
+  roots[1] = 0.5f * (b - sd);
+}
+
+/* computeRoots (eigen.h:122-185): closed-form eigenvalues of a symmetric 3x3, ascending, fp32 */
+static void eig_roots3(const float m[9], float roots[3]) {
+  float c0 = m[0] * m[4] * m[8] + 2.f * m[1] * m[2] * m[5] - m[0] * m[5] * m[5] - m[4] * m[2] * m[2] -
+             m[8] * m[1] * m[1];
+  float c1 = m[0] * m[4] - m[1] * m[1] + m[0] * m[8] - m[2] * m[2] + m[4] * m[8] - m[5] * m[5];
+  float c2 = m[0] + m[4] + m[8];
+  if (fabsf(c0) < 1.1920929e-07f) { /* one root is 0 -> quadratic */
+    eig_roots2(c2, c1, roots);
+    return;
+  }
+  const float s_inv3 = (float)(1.0 / 3.0);
+  const float s_sqrt3 = sqrtf(3.0f);
+  float c2_over_3 = c2 * s_inv3;
+  float a_over_3 = (c1 - c2 * c2_over_3) * s_inv3;
+  if (a_over_3 > 0.f) a_over_3 = 0.f;
+  float half_b = 0.5f * (c0 + c2_over_3 * (2.f * c2_over_3 * c2_over_3 - c1));
+  float q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
+  if (q > 0.f) q = 0.f;
+  float rho = sqrtf(-a_over_3);
+  float theta = atan2f(sqrtf(-q), half_b) * s_inv3;
+  float cos_theta = cosf(theta), sin_theta = sinf(theta);
+  roots[0] = c2_over_3 + 2.f * rho * cos_theta;
+  roots[1] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
+  roots[2] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
+  float t;
+  if (roots[0] >= roots[1]) { t = roots[0]; roots[0] = roots[1]; roots[1] = t; }
+  if (roots[1] >= roots[2]) {
+    t = roots[1]; roots[1] = roots[2]; roots[2] = t;
+    if (roots[0] >= roots[1]) { t = roots[0]; roots[0] = roots[1]; roots[1] = t; }
+  }
+  if (roots[0] <= 0.f) eig_roots2(c2, c1, roots);
+}
+
+/* eigen33 (mat, eigenvalue, eigenvector) (eigen.h:334-368): smallest eigenpair */
+static void eigen33_smallest(const float mat[9], float *eigenvalue, float vec[3]) {
+  float scale = 0.f;
+  for (int i = 0; i < 9; ++i) scale = fmaxf(scale, fabsf(mat[i]));
+  if (scale <= 1.17549435e-38f) scale = 1.f;
+  float sm[9];
+  for (int i = 0; i < 9; ++i) sm[i] = mat[i] / scale;
+  float ev[3];
+  eig_roots3(sm, ev);
+  *eigenvalue = ev[0] * scale;
+  sm[0] -= ev[0];
+  sm[4] -= ev[0];
+  sm[8] -= ev[0];
+  const float *r0 = sm, *r1 = sm + 3, *r2 = sm + 6;
+  float v1[3] = {r0[1] * r1[2] - r0[2] * r1[1], r0[2] * r1[0] - r0[0] * r1[2], r0[0] * r1[1] - r0[1] * r1[0]};
+  float v2[3] = {r0[1] * r2[2] - r0[2] * r2[1], r0[2] * r2[0] - r0[0] * r2[2], r0[0] * r2[1] - r0[1] * r2[0]};
+  float v3[3] = {r1[1] * r2[2] - r1[2] * r2[1], r1[2] * r2[0] - r1[0] * r2[2], r1[0] * r2[1] - r1[1] * r2[0]};
+  float l1 = v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2];
+  float l2 = v2[0] * v2[0] + v2[1] * v2[1] + v2[2] * v2[2];
+  float l3 = v3[0] * v3[0] + v3[1] * v3[1] + v3[2] * v3[2];
+  const float *best;
+  float len;
+  if (l1 >= l2 && l1 >= l3) { best = v1; len = l1; }
+  else if (l2 >= l1 && l2 >= l3) { best = v2; len = l2; }
+  else { best = v3; len = l3; }
+  float s = sqrtf(len);
+  for (int d = 0; d < 3; ++d) vec[d] = best[d] / s;
+}
+
+int orc_point_normal(const float *pts, int ps, const int32_t *idx, int64_t n, float plane[4],
+                     float *curvature) {
+  /* computeMeanAndCovarianceMatrix (centroid.hpp:553-617): nine fp32 running sums, then / n */
+  float accu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int64_t cnt = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    const float *p = pts + (size_t)(idx ? idx[i] : i) * ps;
+    if (!isfinite(p[0]) || !isfinite(p[1]) || !isfinite(p[2])) continue;
+    ++cnt;
+    accu[0] += p[0] * p[0];
+    accu[1] += p[0] * p[1];
+    accu[2] += p[0] * p[2];
+    accu[3] += p[1] * p[1];
+    accu[4] += p[1] * p[2];
+    accu[5] += p[2] * p[2];
+    accu[6] += p[0];
+    accu[7] += p[1];
+    accu[8] += p[2];
+  }
+  if (cnt == 0) {
+    plane[0] = plane[1] = plane[2] = plane[3] = *curvature = NAN;
+    return 0;
+  }
+  for (int i = 0; i < 9; ++i) accu[i] /= (float)cnt;
+  float cov[9];
+  cov[0] = accu[0] - accu[6] * accu[6];
+  cov[1] = accu[1] - accu[6] * accu[7];
+  cov[2] = accu[2] - accu[6] * accu[8];
+  cov[4] = accu[3] - accu[7] * accu[7];
+  cov[5] = accu[4] - accu[7] * accu[8];
+  cov[8] = accu[5] - accu[8] * accu[8];
+  cov[3] = cov[1];
+  cov[6] = cov[2];
+  cov[7] = cov[5];
+  /* solvePlaneParameters (feature.hpp:47-86) */
+  float ev, vec[3];
+  eigen33_smallest(cov, &ev, vec);
+  plane[0] = vec[0];
+  plane[1] = vec[1];
+  plane[2] = vec[2];
+  float eig_sum = cov[0] + cov[4] + cov[8];
+  *curvature = eig_sum != 0.f ? fabsf(ev / eig_sum) : 0.f;
+  plane[3] = -1.f * (plane[0] * accu[6] + plane[1] * accu[7] + plane[2] * accu[8]);
+  return (int)cnt;
+}
+
+int orc_normals(const orc_tree *t, const float *pts, int ps, const float *q, int64_t nq, int qs, int k,
+                double radius, const float vp[3], float *out, int nthreads) {
+  const float r2 = (float)(radius * radius);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 256) num_threads(nthreads > 1 ? nthreads : 1)
+#endif
+  for (int64_t i = 0; i < nq; ++i) {
+    const float *qq = q + (size_t)i * qs;
+    float *o = out + (size_t)i * 4;
+    o[0] = o[1] = o[2] = o[3] = NAN;
+    if (!isfinite(qq[0]) || !isfinite(qq[1]) || !isfinite(qq[2])) continue;
+    int32_t *idx = NULL;
+    float *d2 = NULL;
+    int64_t m = 0;
+    if (k > 0) {
+      int ke = k > t->n ? (int)t->n : k;
+      idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)(ke > 0 ? ke : 1));
+      d2 = (float *)malloc(sizeof(float) * (size_t)(ke > 0 ? ke : 1));
+      m = orc_tree_knn(t, qq, 1, qs, k, idx, d2, 1);
+    } else {
+      int64_t off[2];
+      orc_tree_radius(t, qq, 1, qs, r2, 0, 1, off, &idx, &d2, 1);
+      m = off[1];
+    }
+    if (m > 0) {
+      float plane[4], curv;
+      orc_point_normal(pts, ps, idx, m, plane, &curv);
+      /* flipNormalTowardsViewpoint (normal_3d.h:162-181) */
+      float vx = vp[0] - qq[0], vy = vp[1] - qq[1], vz = vp[2] - qq[2];
+      float cos_theta = (vx * plane[0] + vy * plane[1] + vz * plane[2]);
+      if (cos_theta < 0) {
+        plane[0] *= -1;
+        plane[1] *= -1;
+        plane[2] *= -1;
+      }
+      o[0] = plane[0];
+      o[1] = plane[1];
+      o[2] = plane[2];
+      o[3] = curv;
+    }
+    free(idx);
+    free(d2);
+  }
+  return 0;
+}

@@ -144,6 +144,27 @@ int orc_icp_align(const orc_icp_params *p, const float *src, int64_t ns, int sst
 double orc_fitness_score(const float *src, int64_t ns, int sstride, const float *tgt,
                          int64_t nt, int tstride, const float final_T[16], double max_range);
 
+/* ---- surface normals (the largest caller of the batched searches) ---- */
+
+/* computePointNormal on an index list (features/include/pcl/features/normal_3d.h:88-104):
+ * computeMeanAndCovarianceMatrix in fp32, sequential in list order
+ * (common/include/pcl/common/impl/centroid.hpp:553-617), then solvePlaneParameters
+ * (features/include/pcl/features/impl/feature.hpp:47-86) = pcl::eigen33 closed-form smallest
+ * eigenpair (common/include/pcl/common/eigen.h:105-190,334-368) and curvature
+ * |lambda0 / trace|.  plane[4] = (nx, ny, nz, d) with d = -n . centroid.  Returns the number of
+ * points used (0: plane / curvature are NaN).  Sign of the normal is the solver's own. */
+int orc_point_normal(const float *pts, int pstride, const int32_t *idx, int64_t n, float plane[4],
+                     float *curvature);
+
+/* NormalEstimation::computeFeature (features/include/pcl/features/impl/normal_3d.hpp:46-98) over
+ * queries q against the surface cloud pts: neighbours = k nearest (k > 0) or all within radius
+ * (k == 0, radius > 0), ascending by (d2, index); normal flipped towards the viewpoint
+ * (flipNormalTowardsViewpoint, normal_3d.h:162-181).  out = nq x (nx, ny, nz, curvature); rows
+ * without neighbours or with a non-finite query are NaN.  Returns 0. */
+int orc_normals(const orc_tree *t, const float *pts, int pstride, const float *q, int64_t nq,
+                int qstride, int k, double radius, const float viewpoint[3], float *out,
+                int nthreads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -99,6 +99,11 @@ def lib():
                                     c_f32p, c_f32p, C.POINTER(IcpStats), C.c_int]
         L.orc_fitness_score.restype = C.c_double
         L.orc_fitness_score.argtypes = [c_f32p, c_i64, C.c_int, c_f32p, c_i64, C.c_int, c_f32p, C.c_double]
+        L.orc_point_normal.restype = C.c_int
+        L.orc_point_normal.argtypes = [c_f32p, C.c_int, c_i32p, c_i64, c_f32p, c_f32p]
+        L.orc_normals.restype = C.c_int
+        L.orc_normals.argtypes = [C.c_void_p, c_f32p, C.c_int, c_f32p, c_i64, C.c_int, C.c_int, C.c_double, c_f32p,
+                                  c_f32p, C.c_int]
         _LIB = L
     return _LIB
 
@@ -178,6 +183,31 @@ class Tree:
         lib().orc_tree_radius(self.h, _p(queries, c_f32p), nq, queries.shape[1], r2, max_nn, int(sorted_results),
                               _p(offsets, c_i64p), C.byref(pi), C.byref(pd), nthreads)
         return _collect(offsets, pi, pd)
+
+
+def point_normal(pts, idx=None):
+    """computePointNormal on an index list (None = the whole cloud): (plane[4], curvature, count)."""
+    pts = _f32(pts)
+    plane = np.zeros(4, np.float32)
+    curv = np.zeros(1, np.float32)
+    if idx is None:
+        n, ip = len(pts), None
+    else:
+        ii = np.ascontiguousarray(idx, np.int32)
+        n, ip = len(ii), _p(ii, c_i32p)
+    cnt = lib().orc_point_normal(_p(pts, c_f32p), pts.shape[1], ip, n, _p(plane, c_f32p), _p(curv, c_f32p))
+    return plane, float(curv[0]), cnt
+
+
+def normals(tree, queries, k=0, radius=0.0, viewpoint=(0.0, 0.0, 0.0), nthreads=1):
+    """NormalEstimation::computeFeature over `queries` against the cloud of `tree` (a Tree)."""
+    queries = _f32(queries)
+    out = np.full((len(queries), 4), np.nan, np.float32)
+    vp = np.ascontiguousarray(viewpoint, np.float32)
+    if len(queries):
+        lib().orc_normals(tree.h, _p(tree.pts, c_f32p), tree.pts.shape[1], _p(queries, c_f32p), len(queries),
+                          queries.shape[1], int(k), float(radius), _p(vp, c_f32p), _p(out, c_f32p), nthreads)
+    return out
 
 
 def transform(pts, T):

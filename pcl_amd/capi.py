@@ -101,6 +101,11 @@ SIGNATURES = {
     "pclmi_icp_solve": (C.c_int, [c_f64p, c_f32p]),
     "pclmi_icp_set_transform": (C.c_int, [C.c_void_p, c_f32p]),
     "pclmi_icp_end": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pclmi_normals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_double, c_f32p,
+                                C.c_void_p]),
+    "pclmi_normals_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_double, c_f32p,
+                                    C.c_void_p, C.c_void_p]),
+    "pclmi_point_normal": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, c_f32p, c_f32p]),
     "pclmi_icp_set_criteria": (C.c_int, [C.c_void_p, C.POINTER(IcpParams)]),
     "pclmi_icp_solve_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "pclmi_icp_run_dev": (C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_void_p]),
@@ -240,6 +245,28 @@ class Tree:
         lib.pclmi_free(pi)
         lib.pclmi_free(pd)
         return offsets.astype(np.int64), idx, d2
+
+
+def normals(surface_tree, queries, k=0, radius=0.0, viewpoint=(0.0, 0.0, 0.0)):
+    """pcl::NormalEstimation over `queries` against the surface tree: [nq, 4] = (nx, ny, nz, curvature)."""
+    q = _pts(queries)
+    out = np.full((len(q), 4), np.nan, np.float32)
+    vp = np.ascontiguousarray(viewpoint, np.float32)
+    _check(load_library().pclmi_normals(surface_tree.h, q.ctypes.data, len(q), q.shape[1] * 4, int(k), float(radius),
+                                        vp.ctypes.data_as(c_f32p), out.ctypes.data))
+    return out
+
+
+def point_normal(points, indices=None):
+    """pcl::computePointNormal: (plane[4], curvature) of one index list (None = the whole cloud)."""
+    p = _pts(points)
+    plane = np.zeros(4, np.float32)
+    curv = C.c_float(0)
+    ii = None if indices is None else np.ascontiguousarray(indices, np.int32)
+    _check(load_library().pclmi_point_normal(p.ctypes.data, len(p), p.shape[1] * 4,
+                                             None if ii is None else ii.ctypes.data, 0 if ii is None else len(ii),
+                                             plane.ctypes.data_as(c_f32p), C.byref(curv)))
+    return plane, curv.value
 
 
 def correspondences(target_tree, src, max_distance=float(np.sqrt(np.finfo(np.float64).max)), src_indices=None):

@@ -225,6 +225,10 @@ int select_flagged(const int *d_in, const unsigned char *d_flags, size_t n, int 
                    size_t tmp_bytes, size_t *need, hipStream_t s);
 void launch_fitness(const float *d_d2, size_t n, double max_range, double *d_out2, hipStream_t s);
 
+// ---- surface normals (normal_kernels.hip): idx is CSR (d_offsets != null) or nq rows of k entries ----
+void launch_normals(const pclmi_tree *t, const float *d_q, size_t q_stride_f, size_t nq, const int *d_idx,
+                    const uint64_t *d_offsets, int k, const float vp[3], float *d_out, hipStream_t s);
+
 // ---- host math (registration_host.cpp; needs no GPU) ----------------------------------------
 void svd3_f64(const double A[9], double U[9], double S[3], double V[9]);
 int solve_rigid_from_sums(const double sums[PCLMI_ICP_NSUMS], float T[16]);

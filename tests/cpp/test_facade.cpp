@@ -14,6 +14,7 @@
 
 #include <pcl/common/time.h>
 #include <pcl/common/transforms.h>
+#include <pcl/features/normal_3d.h>
 #include <pcl/kdtree/kdtree_flann.h>
 #include <pcl/point_types.h>
 #include <pcl/registration/correspondence_estimation.h>
@@ -25,6 +26,7 @@
 #include <pcl/registration/correspondence_rejection_var_trimmed.h>
 #include <pcl/registration/icp.h>
 #include <pcl/registration/transformation_estimation_svd.h>
+#include <pcl/search/flann_search.h>
 #include <pcl/search/kdtree.h>
 
 using namespace pcl;
@@ -237,6 +239,130 @@ TEST(SearchKdTree_batch_equals_single) {
   for (size_t j = 0; j < si.size(); ++j) EXPECT(si[j] % 3 == 0);
 }
 
+// ---- test/search/test_flann_search.cpp:129-364 : FlannSearch agrees with search::KdTree ------------
+TEST(FlannSearch_equals_KdTree) {
+  PointCloud<PointXYZ>::Ptr cloud(new PointCloud<PointXYZ>);
+  std::srand(11);
+  for (int i = 0; i < 2000; ++i)
+    cloud->push_back(PointXYZ(float(1024 * (std::rand() / (RAND_MAX + 1.0))), float(1024 * (std::rand() / (RAND_MAX + 1.0))),
+                              float(1024 * (std::rand() / (RAND_MAX + 1.0)))));
+  search::KdTree<PointXYZ> kd;
+  search::FlannSearch<PointXYZ> fl(true, new search::FlannSearch<PointXYZ>::KdTreeIndexCreator(15));
+  search::Search<PointXYZ> *base = &fl;  // used through the abstract interface, as Feature does
+  kd.setInputCloud(cloud);
+  base->setInputCloud(cloud);
+  EXPECT(base->getName() == "FlannSearch" && kd.getName() == "KdTree");
+  std::vector<int> all, a, b;
+  std::vector<float> da, db;
+  std::vector<std::vector<int> > bi, fi;
+  std::vector<std::vector<float> > bd, fd;
+  kd.nearestKSearch(*cloud, all, 7, bi, bd);       // empty index list = every point (search.h:250-255)
+  base->nearestKSearch(*cloud, all, 7, fi, fd);
+  EXPECT(bi.size() == 2000 && bi == fi && bd == fd);
+  for (int i = 0; i < 2000; i += 97) {
+    EXPECT_EQ(kd.nearestKSearch(cloud->points[i], 7, a, da), 7);
+    EXPECT_EQ(base->nearestKSearch(cloud->points[i], 7, b, db), 7);
+    EXPECT(a == b && da == db && a == fi[i]);
+    EXPECT_EQ(kd.radiusSearch(cloud->points[i], 80.0, a, da, 0), base->radiusSearch(cloud->points[i], 80.0, b, db, 0));
+    EXPECT(a == b && da == db);
+  }
+  kd.radiusSearch(*cloud, all, 50.0, bi, bd, 10);
+  base->radiusSearch(*cloud, all, 50.0, fi, fd, 10);
+  EXPECT(bi == fi && bd == fd);
+  fl.setEpsilon(0.5);  // accepted, still exact
+  EXPECT_EQ(fl.nearestKSearch(cloud->points[3], 7, b, db), 7);
+  kd.nearestKSearch(cloud->points[3], 7, a, da);
+  EXPECT(a == b);
+}
+
+// ---- test/features/test_normal_estimation.cpp:56-150 ---------------------------------------------
+TEST(NormalEstimation_bun0) {
+  const PointCloud<PointXYZ> &cloud = cloud_source;  // bun0.pcd, as the reference test's argv[1]
+  std::vector<int> indices(cloud.points.size());
+  for (size_t i = 0; i < indices.size(); ++i) indices[i] = int(i);
+  search::KdTree<PointXYZ>::Ptr tree(new search::KdTree<PointXYZ>(false));
+  tree->setInputCloud(cloud.makeShared());
+  Vector4f plane_parameters;
+  float curvature;
+  NormalEstimation<PointXYZ, Normal> n;
+  computePointNormal(cloud, indices, plane_parameters, curvature);  // (indices, Vector)
+  EXPECT_NEAR(std::fabs(plane_parameters[0]), 0.035592, 1e-4);
+  EXPECT_NEAR(std::fabs(plane_parameters[1]), 0.369596, 1e-4);
+  EXPECT_NEAR(std::fabs(plane_parameters[2]), 0.928511, 1e-4);
+  EXPECT_NEAR(std::fabs(plane_parameters[3]), 0.0622552, 1e-4);
+  EXPECT_NEAR(curvature, 0.0693136, 1e-4);
+  float nx, ny, nz;
+  n.computePointNormal(cloud, indices, nx, ny, nz, curvature);  // (indices)
+  EXPECT_NEAR(std::fabs(nx), 0.035592, 1e-4);
+  EXPECT_NEAR(std::fabs(ny), 0.369596, 1e-4);
+  EXPECT_NEAR(std::fabs(nz), 0.928511, 1e-4);
+  EXPECT_NEAR(curvature, 0.0693136, 1e-4);
+  computePointNormal(cloud, plane_parameters, curvature);  // (Vector): the sign is the solver's own
+  const float sg = plane_parameters[2] < 0 ? -1.f : 1.f;
+  EXPECT_NEAR(sg * plane_parameters[0], 0.035592, 1e-4);
+  EXPECT_NEAR(sg * plane_parameters[1], 0.369596, 1e-4);
+  EXPECT_NEAR(sg * plane_parameters[2], 0.928511, 1e-4);
+  EXPECT_NEAR(sg * plane_parameters[3], -0.0622552, 1e-4);
+  EXPECT_NEAR(curvature, 0.0693136, 1e-4);
+  if (sg < 0) for (int d = 0; d < 4; ++d) plane_parameters[d] = -plane_parameters[d];
+  flipNormalTowardsViewpoint(cloud.points[0], 0, 0, 0, plane_parameters);  // (Vector)
+  EXPECT_NEAR(plane_parameters[0], -0.035592, 1e-4);
+  EXPECT_NEAR(plane_parameters[1], -0.369596, 1e-4);
+  EXPECT_NEAR(plane_parameters[2], -0.928511, 1e-4);
+  EXPECT_NEAR(plane_parameters[3], 0.0799743, 1e-4);
+  nx = std::fabs(nx); ny = std::fabs(ny); nz = std::fabs(nz);
+  flipNormalTowardsViewpoint(cloud.points[0], 0, 0, 0, nx, ny, nz);
+  EXPECT_NEAR(nx, -0.035592, 1e-4);
+  EXPECT_NEAR(ny, -0.369596, 1e-4);
+  EXPECT_NEAR(nz, -0.928511, 1e-4);
+  // Object
+  PointCloud<Normal>::Ptr normals(new PointCloud<Normal>());
+  PointCloud<PointXYZ>::Ptr cloudptr = cloud.makeShared();
+  n.setInputCloud(cloudptr);
+  EXPECT(n.getInputCloud() == cloudptr);
+  IndicesPtr indicesptr(new std::vector<int>(indices));
+  n.setIndices(indicesptr);
+  EXPECT(n.getIndices() == indicesptr);
+  n.setSearchMethod(tree);
+  EXPECT(n.getSearchMethod() == tree);
+  n.setKSearch(int(indices.size()));
+  n.compute(*normals);
+  EXPECT_EQ(normals->points.size(), indices.size());
+  for (size_t i = 0; i < normals->points.size(); ++i) {
+    EXPECT_NEAR(normals->points[i].normal[0], -0.035592, 1e-4);
+    EXPECT_NEAR(normals->points[i].normal[1], -0.369596, 1e-4);
+    EXPECT_NEAR(normals->points[i].normal[2], -0.928511, 1e-4);
+    EXPECT_NEAR(normals->points[i].curvature, 0.0693136, 1e-4);
+  }
+  // a search surface and a subset of the input (:127-150): results for the subset equal the full run's rows
+  PointCloud<PointXYZ>::Ptr surfaceptr = cloudptr;
+  n.setSearchSurface(surfaceptr);
+  EXPECT(n.getSearchSurface() == surfaceptr);
+  n.setKSearch(12);
+  PointCloud<Normal> full, part;
+  n.compute(full);
+  IndicesPtr some(new std::vector<int>);
+  for (int i = 0; i < 397; i += 5) some->push_back(i);
+  n.setIndices(some);
+  n.compute(part);
+  EXPECT_EQ(part.points.size(), some->size());
+  EXPECT(part.width == some->size() && part.height == 1 && full.width == 397);
+  for (size_t i = 0; i < some->size(); ++i)
+    EXPECT(part.points[i].normal_x == full.points[(*some)[i]].normal_x && part.points[i].curvature == full.points[(*some)[i]].curvature);
+  // the OpenMP variant is the same device batch; neither k nor radius -> empty output (feature.hpp:158-167)
+  NormalEstimationOMP<PointXYZ, Normal> no(4);
+  no.setInputCloud(cloudptr);
+  no.setKSearch(12);
+  PointCloud<Normal> omp;
+  no.compute(omp);
+  EXPECT(omp.points.size() == 397 && omp.points[3].normal_y == full.points[3].normal_y);
+  console::setVerbosityLevel(console::L_ALWAYS);
+  no.setKSearch(0);
+  no.compute(omp);
+  EXPECT(omp.points.empty() && omp.width == 0);
+  console::setVerbosityLevel(console::L_INFO);
+}
+
 // ---- test/registration/test_registration_api.cpp ---------------------------------------------------
 static bool pairsEqual(const Correspondences &c, const std::vector<double> &gold, bool check_query) {
   if (c.size() * 2 != gold.size()) return false;
@@ -390,6 +516,8 @@ int main(int argc, char **argv) {
   RUN(KdTreeFLANN_nearestKSearch);
   RUN(KdTreeFLANN_setPointRepresentation);
   RUN(SearchKdTree_batch_equals_single);
+  RUN(FlannSearch_equals_KdTree);
+  RUN(NormalEstimation_bun0);
   RUN(RegistrationAPI);
   RUN(IterativeClosestPointGolden);
   std::printf("%d checks, %d failed\n", g_checks, g_fail);

@@ -85,3 +85,13 @@ def test_default_params_match_reference_defaults():
     assert p.euclidean_fitness_epsilon == -np.finfo(np.float64).max
     assert p.max_correspondence_distance == np.sqrt(np.finfo(np.float64).max)
     assert C.sizeof(capi.IcpParams) == 48 and C.sizeof(capi.IcpStats) == 32
+
+
+def test_point_normal_needs_no_gpu_and_matches_the_reference_golden():
+    """pclmi_point_normal is host code: test/features/test_normal_estimation.cpp:64-70 on bun0."""
+    from pcl_amd import capi
+    plane, curv = capi.point_normal(util.bun0())
+    assert np.abs(np.abs(plane) - [0.035592, 0.369596, 0.928511, 0.0622552]).max() <= 1e-4
+    assert abs(curv - 0.0693136) <= 1e-4
+    empty, c0 = capi.point_normal(np.full((3, 3), np.nan, np.float32))
+    assert np.isnan(empty).all() and np.isnan(c0)

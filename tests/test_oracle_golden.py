@@ -155,3 +155,22 @@ def test_tree_vs_brute_random_dense_and_radius_variants():
             assert np.array_equal(bo, to) and np.array_equal(bi, ti) and np.array_equal(bd, td)
             if max_nn:
                 assert np.all(np.diff(bo) <= max_nn)
+
+
+def test_normal_estimation_golden():
+    """test/features/test_normal_estimation.cpp:56-125: bun0, all 397 points -> plane (0.035592, 0.369596,
+    0.928511, -0.0622552), curvature 0.0693136 (1e-4); NormalEstimation with k = 397 and the viewpoint at the
+    origin gives the flipped normal for every point."""
+    from oracle import pcl_oracle as orc
+    b = util.bun0()
+    plane, curv, cnt = orc.point_normal(b)
+    assert cnt == 397
+    assert np.abs(np.abs(plane) - [0.035592, 0.369596, 0.928511, 0.0622552]).max() <= 1e-4
+    assert abs(curv - 0.0693136) <= 1e-4
+    plane_i, curv_i, _ = orc.point_normal(b, np.arange(397, dtype=np.int32))
+    assert np.array_equal(plane, plane_i) and curv == curv_i
+    n = orc.normals(orc.Tree(b), b, k=397)
+    assert np.abs(n - [-0.035592, -0.369596, -0.928511, 0.0693136]).max() <= 1e-4
+    # rows without neighbours / non-finite queries are NaN (normal_3d.hpp:62-68)
+    q = np.array([[5, 5, 5], [np.nan, 0, 0]], np.float32)
+    assert np.isnan(orc.normals(orc.Tree(b), q, radius=0.01)).all()
