@@ -125,6 +125,10 @@ void *dev_cache_get(size_t bytes) {
     }
   }
   std::lock_guard<std::mutex> g(g_cmu);
+  // a pointer HIP just handed out cannot be live anywhere else: drop any stale record of it (a caller that
+  // released a result buffer with hipFree instead of pclmi_free_dev would otherwise poison the size lookup)
+  for (size_t i = g_handed.size(); i-- > 0;)
+    if (g_handed[i].p == p) g_handed.erase(g_handed.begin() + i);
   g_handed.push_back(CacheEntry{p, cap, dev});
   return p;
 }

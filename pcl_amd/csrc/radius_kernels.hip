@@ -488,8 +488,8 @@ int pclmi_radius(const pclmi_tree *t, const float *q, size_t nq, size_t q_stride
   }
   if (d_q) (void)hipFree(d_q);
   if (d_off) (void)hipFree(d_off);
-  if (d_idx) (void)hipFree(d_idx);
-  if (d_d2) (void)hipFree(d_d2);
+  pclmi_free_dev(d_idx);  // result buffers belong to the library's cache (never hipFree them directly)
+  pclmi_free_dev(d_d2);
   return rc;
 }
 
