@@ -41,6 +41,26 @@
 #include "traverse.hpp"
 
 namespace pclmi {
+#ifdef PCLMI_STATS
+// development counters (make variant NAME=stats EXTRA=-DPCLMI_STATS): per-launch totals over all waves
+__device__ unsigned long long g_knn_stats[8];  // 0 leaves, 1 leaf groups with any pass, 2 chain executions,
+                                               // 3 compactions, 4 inner expansions, 6 waves
+extern "C" void pclmi_debug_knn_stats(unsigned long long out[8], int reset) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_knn_stats), sizeof(unsigned long long) * 8);
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_knn_stats), z, sizeof(z));
+  }
+}
+#define PCLMI_STAT(i, v)                                                  \
+  do {                                                                    \
+    if ((threadIdx.x & 63) == 0) atomicAdd(&g_knn_stats[i], (unsigned long long)(v)); \
+  } while (0)
+#else
+#define PCLMI_STAT(i, v) \
+  do {                   \
+  } while (0)
+#endif
 namespace {
 
 using namespace dev;
@@ -172,6 +192,7 @@ __global__ __launch_bounds__(64 * WPB) void knn_union_ix_kernel(TreeView t, cons
       for (int g = 0; g < G; ++g) grp[g] = rec[g];
       const float md = box_dist(qx, qy, qz, b[0], b[1], b[2], b[3], b[4], b[5]);
       if (!__any(md <= a[K - 1])) continue;
+      PCLMI_STAT(0, 1);
       const f2v q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
 #pragma unroll
       for (int g = 0; g < G; ++g) {
@@ -189,6 +210,7 @@ __global__ __launch_bounds__(64 * WPB) void knn_union_ix_kernel(TreeView t, cons
           const float d = dd[j];
           const bool pass = d <= a[K - 1];
           if (__any(pass)) {
+            PCLMI_STAT(2, 1);
             if (pass) {
               buf[cnt][lane] = (unsigned int)(node - M) * L + g * 4 + j;  // bucket slot
               ++cnt;
@@ -196,12 +218,17 @@ __global__ __launch_bounds__(64 * WPB) void knn_union_ix_kernel(TreeView t, cons
             list_insert<K>(a, d);
           }
         }
-        if (__any(cnt > C - 4)) cnt = compact_index_buffer<K, C>(buf, cloud, qx, qy, qz, lane, cnt, a[K - 1], dk, ik, false);
+        if (__any(cnt > C - 4)) {
+          PCLMI_STAT(3, 1);
+          cnt = compact_index_buffer<K, C>(buf, cloud, qx, qy, qz, lane, cnt, a[K - 1], dk, ik, false);
+        }
       }
     } else {
+      PCLMI_STAT(4, 1);
       expand_inner(st, box2, node, M, qx, qy, qz, a[K - 1]);
     }
   }
+  PCLMI_STAT(6, 1);
 
   // ---- final: filter with the exact k-th distance, sort the survivors by (d2, index)
   cnt = compact_index_buffer<K, C>(buf, cloud, qx, qy, qz, lane, cnt, a[K - 1], dk, ik, true);
