@@ -317,6 +317,34 @@ int pclmi_normals_dev(const pclmi_tree *surface, const float *d_queries, size_t 
 int pclmi_point_normal(const float *pts, size_t n_rows, size_t stride_bytes, const int32_t *indices,
                        size_t n_indices, float plane[4], float *curvature);
 
+/* Point-to-plane pieces -------------------------------------------------
+ * Replaces TransformationEstimationPointToPlaneLLS::estimateRigidTransformation
+ * (registration/include/pcl/registration/impl/transformation_estimation_point_to_plane_lls.hpp:
+ * 45-245): linearised point-to-plane least squares over n pairs (src[src_idx[i]], tgt[tgt_idx[i]]
+ * with the target normal tgt_normals[tgt_idx[i]]; index lists nullable = 0..n-1): the 6x6 normal
+ * equations are reduced on the GPU in fp64, solved on the host, T = constructTransformationMatrix
+ * (alpha, beta, gamma, tx, ty, tz) (:118-139).  Pairs with a non-finite coordinate or normal are
+ * skipped (:156-172; src_normals is only consulted for that test and may be NULL).  Returns
+ * PCLMI_ERR_NOT_ENOUGH (T = identity) when the system is singular. */
+int pclmi_estimate_point_to_plane_lls(const float *src, size_t n_src, size_t src_stride_bytes,
+                                      const float *src_normals, size_t sn_stride_bytes,
+                                      const int32_t *src_idx, const float *tgt, size_t n_tgt,
+                                      size_t tgt_stride_bytes, const float *tgt_normals,
+                                      size_t tn_stride_bytes, const int32_t *tgt_idx, size_t n,
+                                      float T[16]);
+/* Replaces CorrespondenceEstimationNormalShooting::determineCorrespondences
+ * (registration/include/pcl/registration/impl/correspondence_estimation_normal_shooting.hpp:60-165):
+ * for every source point, among its k nearest target points (one batched search) the one closest to
+ * the line through the source point along its normal - |N x V|^2 in fp64 rounded to fp32, first
+ * minimum in ascending-distance order; the pair is dropped when that value exceeds max_distance
+ * (compared as the reference compares it: not squared); distance = squared point distance of the
+ * chosen neighbour.  out has capacity n_src (or n_indices); pairs come in source order. */
+int pclmi_correspondences_normal_shooting(const pclmi_tree *target, const float *src, size_t n_src,
+                                          size_t stride_bytes, const float *src_normals,
+                                          size_t sn_stride_bytes, const int32_t *src_indices,
+                                          size_t n_indices, int k, double max_distance,
+                                          pclmi_correspondence *out, size_t *n_out);
+
 #ifdef __cplusplus
 }
 #endif

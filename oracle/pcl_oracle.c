@@ -1357,3 +1357,120 @@ int orc_normals(const orc_tree *t, const float *pts, int ps, const float *q, int
   }
   return 0;
 }
+
+/* ===========================================================================================
+ * Point-to-plane pieces
+ * =========================================================================================== */
+
+/* x = A^-1 b for a 6x6 by Gauss-Jordan with partial pivoting (stands in for Eigen's ATA.inverse () * ATb) */
+static int solve6(double A[36], double b[6], double x[6]) {
+  double M[6][7];
+  for (int r = 0; r < 6; ++r) {
+    for (int c = 0; c < 6; ++c) M[r][c] = A[r * 6 + c];
+    M[r][6] = b[r];
+  }
+  for (int c = 0; c < 6; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < 6; ++r)
+      if (fabs(M[r][c]) > fabs(M[piv][c])) piv = r;
+    if (M[piv][c] == 0.0) return -1;
+    if (piv != c)
+      for (int k = 0; k < 7; ++k) { double t = M[c][k]; M[c][k] = M[piv][k]; M[piv][k] = t; }
+    for (int r = 0; r < 6; ++r) {
+      if (r == c) continue;
+      double f = M[r][c] / M[c][c];
+      for (int k = c; k < 7; ++k) M[r][k] -= f * M[c][k];
+    }
+  }
+  for (int r = 0; r < 6; ++r) x[r] = M[r][6] / M[r][r];
+  return 0;
+}
+
+void orc_estimate_point_to_plane_lls(const float *src, int ss, const float *sn, int sns, const int32_t *sidx,
+                                     const float *tgt, int ts, const float *tn, int tns, const int32_t *tidx,
+                                     int64_t n, float T[16]) {
+  double ATA[36], ATb[6];
+  memset(ATA, 0, sizeof(ATA));
+  memset(ATb, 0, sizeof(ATb));
+  for (int64_t i = 0; i < n; ++i) {
+    const size_t si = (size_t)(sidx ? sidx[i] : i), ti = (size_t)(tidx ? tidx[i] : i);
+    const float *s = src + si * ss, *d = tgt + ti * ts, *nn = tn + ti * tns;
+    int ok = isfinite(s[0]) && isfinite(s[1]) && isfinite(s[2]) && isfinite(d[0]) && isfinite(d[1]) &&
+             isfinite(d[2]) && isfinite(nn[0]) && isfinite(nn[1]) && isfinite(nn[2]);
+    if (ok && sn) {
+      const float *m = sn + si * sns;
+      ok = isfinite(m[0]) && isfinite(m[1]) && isfinite(m[2]);
+    }
+    if (!ok) continue;
+    const float sx = s[0], sy = s[1], sz = s[2], dx = d[0], dy = d[1], dz = d[2];
+    const float nx = nn[0], ny = nn[1], nz = nn[2];
+    double a = nz * sy - ny * sz; /* fp32 expressions widened on assignment, as the reference writes them */
+    double b = nx * sz - nz * sx;
+    double c = ny * sx - nx * sy;
+    ATA[0] += a * a;  ATA[1] += a * b;  ATA[2] += a * c;  ATA[3] += a * nx;  ATA[4] += a * ny;  ATA[5] += a * nz;
+    ATA[7] += b * b;  ATA[8] += b * c;  ATA[9] += b * nx; ATA[10] += b * ny; ATA[11] += b * nz;
+    ATA[14] += c * c; ATA[15] += c * nx; ATA[16] += c * ny; ATA[17] += c * nz;
+    ATA[21] += nx * nx; ATA[22] += nx * ny; ATA[23] += nx * nz;
+    ATA[28] += ny * ny; ATA[29] += ny * nz;
+    ATA[35] += nz * nz;
+    double dd = nx * dx + ny * dy + nz * dz - nx * sx - ny * sy - nz * sz;
+    ATb[0] += a * dd; ATb[1] += b * dd; ATb[2] += c * dd; ATb[3] += nx * dd; ATb[4] += ny * dd; ATb[5] += nz * dd;
+  }
+  for (int r = 0; r < 6; ++r)
+    for (int c = 0; c < r; ++c) ATA[r * 6 + c] = ATA[c * 6 + r];
+  double x[6] = {0, 0, 0, 0, 0, 0};
+  mat4_identity(T);
+  if (solve6(ATA, ATb, x) != 0) return;
+  const double al = x[0], be = x[1], ga = x[2];
+  T[0] = (float)(cos(ga) * cos(be));
+  T[1] = -(float)(sin(ga) * cos(al) + cos(ga) * sin(be) * sin(al));
+  T[2] = (float)(sin(ga) * sin(al) + cos(ga) * sin(be) * cos(al));
+  T[4] = (float)(sin(ga) * cos(be));
+  T[5] = (float)(cos(ga) * cos(al) + sin(ga) * sin(be) * sin(al));
+  T[6] = -(float)(cos(ga) * sin(al) + sin(ga) * sin(be) * cos(al));
+  T[8] = -(float)(sin(be));
+  T[9] = (float)(cos(be) * sin(al));
+  T[10] = (float)(cos(be) * cos(al));
+  T[3] = (float)x[3];
+  T[7] = (float)x[4];
+  T[11] = (float)x[5];
+  T[15] = 1.f;
+}
+
+int64_t orc_correspondences_normal_shooting(const float *src, int64_t ns, int ss, const float *sn, int sns,
+                                            const float *tgt, int64_t nt, int ts, int k, double max_distance,
+                                            orc_corr *out) {
+  if (nt == 0 || k <= 0) return 0;
+  orc_tree *t = orc_tree_build(tgt, nt, ts, 15);
+  int ke = k > nt ? (int)nt : k;
+  int32_t *idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)ke);
+  float *d2 = (float *)malloc(sizeof(float) * (size_t)ke);
+  int64_t cnt = 0;
+  int min_index = 0; /* not reset per point in the reference either (:71) */
+  for (int64_t i = 0; i < ns; ++i) {
+    const float *p = src + (size_t)i * ss, *nrm = sn + (size_t)i * sns;
+    if (!isfinite(p[0]) || !isfinite(p[1]) || !isfinite(p[2])) continue;
+    int m = orc_tree_knn(t, p, 1, ss, k, idx, d2, 1);
+    float min_dist = FLT_MAX;
+    for (int j = 0; j < m; ++j) {
+      const float *q = tgt + (size_t)idx[j] * ts;
+      const float vx = q[0] - p[0], vy = q[1] - p[1], vz = q[2] - p[2];
+      const double N[3] = {nrm[0], nrm[1], nrm[2]}, V[3] = {vx, vy, vz};
+      const double C[3] = {N[1] * V[2] - N[2] * V[1], N[2] * V[0] - N[0] * V[2], N[0] * V[1] - N[1] * V[0]};
+      const float dist = (float)(C[0] * C[0] + C[1] * C[1] + C[2] * C[2]);
+      if (dist < min_dist) {
+        min_dist = dist;
+        min_index = j;
+      }
+    }
+    if (min_dist > max_distance) continue;
+    out[cnt].index_query = (int32_t)i;
+    out[cnt].index_match = idx[min_index];
+    out[cnt].distance = d2[min_index];
+    ++cnt;
+  }
+  free(idx);
+  free(d2);
+  orc_tree_free(t);
+  return cnt;
+}

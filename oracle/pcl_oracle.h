@@ -165,6 +165,30 @@ int orc_normals(const orc_tree *t, const float *pts, int pstride, const float *q
                 int qstride, int k, double radius, const float viewpoint[3], float *out,
                 int nthreads);
 
+/* ---- point-to-plane registration pieces ---- */
+
+/* TransformationEstimationPointToPlaneLLS::estimateRigidTransformation
+ * (registration/include/pcl/registration/impl/transformation_estimation_point_to_plane_lls.hpp:
+ * 141-245, constructTransformationMatrix :118-139): linearised point-to-plane least squares, 6x6
+ * normal equations accumulated sequentially in fp64, x = ATA^-1 ATb, T from (alpha, beta, gamma, t).
+ * tn = target normals (same rows as tgt).  Pairs with a non-finite coordinate or normal are skipped
+ * (the reference also tests the SOURCE normal; pass sn = NULL when the source has none). */
+void orc_estimate_point_to_plane_lls(const float *src, int sstride, const float *sn, int snstride,
+                                     const int32_t *sidx, const float *tgt, int tstride,
+                                     const float *tn, int tnstride, const int32_t *tidx, int64_t n,
+                                     float T[16]);
+
+/* CorrespondenceEstimationNormalShooting::determineCorrespondences
+ * (registration/include/pcl/registration/impl/correspondence_estimation_normal_shooting.hpp:60-165):
+ * among the k nearest target points of a source point, the one closest to the line through the source
+ * point along its normal (|N x V|^2, first minimum in ascending-distance order); dropped when that
+ * value exceeds max_distance (as the reference compares it: not squared); distance = the squared
+ * point distance of the chosen neighbour.  out must hold ns entries; returns the count. */
+int64_t orc_correspondences_normal_shooting(const float *src, int64_t ns, int sstride,
+                                            const float *sn, int snstride, const float *tgt,
+                                            int64_t nt, int tstride, int k, double max_distance,
+                                            orc_corr *out);
+
 #ifdef __cplusplus
 }
 #endif

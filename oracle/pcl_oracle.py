@@ -99,6 +99,11 @@ def lib():
                                     c_f32p, c_f32p, C.POINTER(IcpStats), C.c_int]
         L.orc_fitness_score.restype = C.c_double
         L.orc_fitness_score.argtypes = [c_f32p, c_i64, C.c_int, c_f32p, c_i64, C.c_int, c_f32p, C.c_double]
+        L.orc_estimate_point_to_plane_lls.argtypes = [c_f32p, C.c_int, c_f32p, C.c_int, c_i32p, c_f32p, C.c_int, c_f32p,
+                                                      C.c_int, c_i32p, c_i64, c_f32p]
+        L.orc_correspondences_normal_shooting.restype = c_i64
+        L.orc_correspondences_normal_shooting.argtypes = [c_f32p, c_i64, C.c_int, c_f32p, C.c_int, c_f32p, c_i64,
+                                                          C.c_int, C.c_int, C.c_double, C.c_void_p]
         L.orc_point_normal.restype = C.c_int
         L.orc_point_normal.argtypes = [c_f32p, C.c_int, c_i32p, c_i64, c_f32p, c_f32p]
         L.orc_normals.restype = C.c_int
@@ -183,6 +188,30 @@ class Tree:
         lib().orc_tree_radius(self.h, _p(queries, c_f32p), nq, queries.shape[1], r2, max_nn, int(sorted_results),
                               _p(offsets, c_i64p), C.byref(pi), C.byref(pd), nthreads)
         return _collect(offsets, pi, pd)
+
+
+def estimate_point_to_plane_lls(src, tgt, tgt_normals, sidx=None, tidx=None, src_normals=None):
+    """TransformationEstimationPointToPlaneLLS on paired points (index lists optional)."""
+    src, tgt, tn = _f32(src), _f32(tgt), _f32(tgt_normals)
+    sn = None if src_normals is None else _f32(src_normals)
+    si = None if sidx is None else np.ascontiguousarray(sidx, np.int32)
+    ti = None if tidx is None else np.ascontiguousarray(tidx, np.int32)
+    n = len(si) if si is not None else (len(ti) if ti is not None else len(src))
+    T = np.zeros(16, np.float32)
+    lib().orc_estimate_point_to_plane_lls(_p(src, c_f32p), src.shape[1], None if sn is None else _p(sn, c_f32p),
+                                          0 if sn is None else sn.shape[1], None if si is None else _p(si, c_i32p),
+                                          _p(tgt, c_f32p), tgt.shape[1], _p(tn, c_f32p), tn.shape[1],
+                                          None if ti is None else _p(ti, c_i32p), n, _p(T, c_f32p))
+    return T.reshape(4, 4)
+
+
+def correspondences_normal_shooting(src, src_normals, tgt, k=10, max_distance=float(np.finfo(np.float64).max)):
+    src, sn, tgt = _f32(src), _f32(src_normals), _f32(tgt)
+    out = np.zeros(len(src), CORR_DTYPE)
+    n = lib().orc_correspondences_normal_shooting(_p(src, c_f32p), len(src), src.shape[1], _p(sn, c_f32p), sn.shape[1],
+                                                  _p(tgt, c_f32p), len(tgt), tgt.shape[1], k, max_distance,
+                                                  out.ctypes.data)
+    return out[:n]
 
 
 def point_normal(pts, idx=None):

@@ -106,6 +106,12 @@ SIGNATURES = {
     "pclmi_normals_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_double, c_f32p,
                                     C.c_void_p, C.c_void_p]),
     "pclmi_point_normal": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, c_f32p, c_f32p]),
+    "pclmi_estimate_point_to_plane_lls": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
+                                                    C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p,
+                                                    C.c_size_t, C.c_void_p, C.c_size_t, c_f32p]),
+    "pclmi_correspondences_normal_shooting": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p,
+                                                        C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_double,
+                                                        C.c_void_p, C.POINTER(C.c_size_t)]),
     "pclmi_icp_set_criteria": (C.c_int, [C.c_void_p, C.POINTER(IcpParams)]),
     "pclmi_icp_solve_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "pclmi_icp_run_dev": (C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_void_p]),
@@ -245,6 +251,37 @@ class Tree:
         lib.pclmi_free(pi)
         lib.pclmi_free(pd)
         return offsets.astype(np.int64), idx, d2
+
+
+def estimate_point_to_plane_lls(src, tgt, tgt_normals, src_idx=None, tgt_idx=None, src_normals=None):
+    """TransformationEstimationPointToPlaneLLS: (status, T[4,4]); status 6 = singular system."""
+    s, t, tn = _pts(src), _pts(tgt), _pts(tgt_normals)
+    sn = None if src_normals is None else _pts(src_normals)
+    si = None if src_idx is None else np.ascontiguousarray(src_idx, np.int32)
+    ti = None if tgt_idx is None else np.ascontiguousarray(tgt_idx, np.int32)
+    n = len(si) if si is not None else (len(ti) if ti is not None else len(s))
+    T = np.zeros(16, np.float32)
+    rc = load_library().pclmi_estimate_point_to_plane_lls(
+        s.ctypes.data, len(s), s.shape[1] * 4, None if sn is None else sn.ctypes.data,
+        0 if sn is None else sn.shape[1] * 4, None if si is None else si.ctypes.data, t.ctypes.data, len(t),
+        t.shape[1] * 4, tn.ctypes.data, tn.shape[1] * 4, None if ti is None else ti.ctypes.data, n,
+        T.ctypes.data_as(c_f32p))
+    if rc not in (0, 6):
+        _check(rc)
+    return rc, T.reshape(4, 4)
+
+
+def correspondences_normal_shooting(target_tree, src, src_normals, k=10,
+                                    max_distance=float(np.finfo(np.float64).max), src_indices=None):
+    s, sn = _pts(src), _pts(src_normals)
+    ii = None if src_indices is None else np.ascontiguousarray(src_indices, np.int32)
+    out = np.zeros(len(s) if ii is None else len(ii), CORR_DTYPE)
+    n = C.c_size_t(0)
+    _check(load_library().pclmi_correspondences_normal_shooting(
+        target_tree.h, s.ctypes.data, len(s), s.shape[1] * 4, sn.ctypes.data, sn.shape[1] * 4,
+        None if ii is None else ii.ctypes.data, 0 if ii is None else len(ii), int(k), float(max_distance),
+        out.ctypes.data, C.byref(n)))
+    return out[:n.value]
 
 
 def normals(surface_tree, queries, k=0, radius=0.0, viewpoint=(0.0, 0.0, 0.0)):

@@ -234,6 +234,7 @@ void svd3_f64(const double A[9], double U[9], double S[3], double V[9]);
 int solve_rigid_from_sums(const double sums[PCLMI_ICP_NSUMS], float T[16]);
 void mat4_mul_f32(const float A[16], const float B[16], float C[16]);
 void sym_eigvals3_f64(const double M[9], double ev[3]);
+int solve_point_to_plane(const double sums[27], float T[16]);
 
 }  // namespace pclmi
 #endif

@@ -24,7 +24,9 @@
 #include <pcl/registration/correspondence_rejection_sample_consensus.h>
 #include <pcl/registration/correspondence_rejection_trimmed.h>
 #include <pcl/registration/correspondence_rejection_var_trimmed.h>
+#include <pcl/registration/correspondence_estimation_normal_shooting.h>
 #include <pcl/registration/icp.h>
+#include <pcl/registration/transformation_estimation_point_to_plane_lls.h>
 #include <pcl/registration/transformation_estimation_svd.h>
 #include <pcl/search/flann_search.h>
 #include <pcl/search/kdtree.h>
@@ -363,6 +365,73 @@ TEST(NormalEstimation_bun0) {
   console::setVerbosityLevel(console::L_INFO);
 }
 
+// ---- test/registration/test_registration.cpp:324-374 ------------------------------------------------
+TEST(TransformationEstimationPointToPlaneLLS_known_motion) {
+  registration::TransformationEstimationPointToPlaneLLS<PointNormal, PointNormal> tform_est;
+  PointCloud<PointNormal>::Ptr src(new PointCloud<PointNormal>);
+  for (float x = -5.0f; x <= 5.0f; x += 0.5f)
+    for (float y = -5.0f; y <= 5.0f; y += 0.5f) {
+      PointNormal p;
+      p.x = x;
+      p.y = y;
+      p.z = 0.1f * powf(x, 2.0f) + 0.2f * p.x * p.y - 0.3f * y + 1.0f;
+      float nx = -0.2f * p.x - 0.2f, ny = 0.6f * p.y - 0.2f, nz = 1.0f;
+      const float magnitude = sqrtf(nx * nx + ny * ny + nz * nz);
+      p.normal_x = nx / magnitude;
+      p.normal_y = ny / magnitude;
+      p.normal_z = nz / magnitude;
+      src->push_back(p);
+    }
+  Matrix4f gt;
+  const float g[16] = {0.9938f, 0.0988f, 0.0517f, 0.1000f, -0.0997f, 0.9949f, 0.0149f, -0.2000f,
+                       -0.0500f, -0.0200f, 0.9986f, 0.3000f, 0.f, 0.f, 0.f, 1.f};
+  for (int i = 0; i < 16; ++i) gt.data()[i] = g[i];
+  PointCloud<PointNormal>::Ptr tgt(new PointCloud<PointNormal>);
+  transformPointCloudWithNormals(*src, *tgt, gt);
+  Matrix4f est;
+  tform_est.estimateRigidTransformation(*src, *tgt, est);
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) EXPECT_NEAR(est(i, j), gt(i, j), 1e-2);
+  // the index-list and correspondence overloads see the same pairs
+  std::vector<int> idx(src->size());
+  Correspondences corr(src->size());
+  for (size_t i = 0; i < idx.size(); ++i) {
+    idx[i] = int(i);
+    corr[i].index_query = corr[i].index_match = int(i);
+  }
+  Matrix4f e2, e3, e4;
+  tform_est.estimateRigidTransformation(*src, idx, *tgt, e2);
+  tform_est.estimateRigidTransformation(*src, idx, *tgt, idx, e3);
+  tform_est.estimateRigidTransformation(*src, *tgt, corr, e4);
+  EXPECT(e2 == est && e3 == est && e4 == est);
+}
+
+// ---- test/test_correspondence_estimation.cpp:45-83 --------------------------------------------------
+TEST(CorrespondenceEstimationNormalShooting_parallel_planes) {
+  PointCloud<PointXYZ>::Ptr cloud1(new PointCloud<PointXYZ>()), cloud2(new PointCloud<PointXYZ>());
+  for (float i = 0; i < 10; i += 0.2f)
+    for (float z = 0; z < 5; z += 0.2f) {
+      cloud1->push_back(PointXYZ(i, 0, z));
+      cloud2->push_back(PointXYZ(i, 2, z));  // the point that should correspond to the one above
+    }
+  NormalEstimation<PointXYZ, Normal> ne;
+  ne.setInputCloud(cloud1);
+  search::KdTree<PointXYZ>::Ptr tree(new search::KdTree<PointXYZ>());
+  ne.setSearchMethod(tree);
+  PointCloud<Normal>::Ptr cloud1_normals(new PointCloud<Normal>);
+  ne.setKSearch(5);
+  ne.compute(*cloud1_normals);  // all normals are perpendicular to the plane
+  CorrespondencesPtr corr(new Correspondences);
+  registration::CorrespondenceEstimationNormalShooting<PointXYZ, PointXYZ, Normal> ce;
+  ce.setInputCloud(cloud1);
+  ce.setKSearch(10);
+  ce.setSourceNormals(cloud1_normals);
+  ce.setInputTarget(cloud2);
+  ce.determineCorrespondences(*corr);
+  EXPECT_EQ(corr->size(), cloud1->size());
+  for (unsigned int i = 0; i < corr->size(); i++) EXPECT_EQ((*corr)[i].index_query, (*corr)[i].index_match);
+}
+
 // ---- test/registration/test_registration_api.cpp ---------------------------------------------------
 static bool pairsEqual(const Correspondences &c, const std::vector<double> &gold, bool check_query) {
   if (c.size() * 2 != gold.size()) return false;
@@ -518,6 +587,8 @@ int main(int argc, char **argv) {
   RUN(SearchKdTree_batch_equals_single);
   RUN(FlannSearch_equals_KdTree);
   RUN(NormalEstimation_bun0);
+  RUN(TransformationEstimationPointToPlaneLLS_known_motion);
+  RUN(CorrespondenceEstimationNormalShooting_parallel_planes);
   RUN(RegistrationAPI);
   RUN(IterativeClosestPointGolden);
   std::printf("%d checks, %d failed\n", g_checks, g_fail);
