@@ -13,7 +13,10 @@
  *    common/include/pcl/impl/point_types.hpp:141-155).  Only the first three floats are read.
  *  - Entry points without a _dev suffix take HOST pointers and copy; _dev entry points take
  *    DEVICE pointers (inputs already resident in HBM) and enqueue on `stream`
- *    (a hipStream_t passed as void*, NULL = the library's stream for that tree).
+ *    (a hipStream_t passed as void*, NULL = the library's stream for that tree).  The search
+ *    entry points (pclmi_knn_dev, pclmi_radius_dev, pclmi_normals_dev) return once their work
+ *    on `stream` has completed (their scratch goes back to a pool); the ICP step / solve entry
+ *    points only enqueue.
  *  - Squared L2 distances are fp32, computed as ((dx*dx + dy*dy) + dz*dz) with one rounding
  *    per operation (flann::L2_Simple<float>, kdtree/include/pcl/kdtree/kdtree_flann.h:56).
  *  - Neighbour lists are ascending in the total order (d2, index): exact search, eps = 0,
