@@ -137,46 +137,100 @@ __global__ __launch_bounds__(64) void segment_sort_kernel(u64 *__restrict__ keys
 // per lane, bitonic network through cross-lane shuffles - no LDS, no barriers.  Counts the segments it
 // leaves to the other two paths: counters[0] = longer than 64, counters[1] = longer than SEG_MAX.
 constexpr int SORT64_WPB = 4;
+// value of lane (lane ^ STRIDE): DPP moves for the strides inside a row of 16 lanes (no LDS crossbar traffic -
+// with a million short segments the ds_bpermute path is the bottleneck), ds_bpermute for 16 and 32
+template <int STRIDE>
+__device__ __forceinline__ unsigned int xor_lane_u32(unsigned int v) {
+  if (STRIDE == 1) return (unsigned int)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);       // quad_perm [1,0,3,2]
+  if (STRIDE == 2) return (unsigned int)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);       // quad_perm [2,3,0,1]
+  if (STRIDE == 4) {
+    const int m = __builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true);                            // row_half_mirror: i ^ 7
+    return (unsigned int)__builtin_amdgcn_mov_dpp(m, 0x1B, 0xF, 0xF, true);                           // quad_perm [3,2,1,0]: ^ 3
+  }
+  if (STRIDE == 8) return (unsigned int)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xF, 0xF, true);      // row_ror:8
+  return (unsigned int)__shfl_xor((int)v, STRIDE);
+}
+
+template <int STRIDE>
+__device__ __forceinline__ u64 xor_lane_u64(u64 k) {
+  const unsigned int lo = xor_lane_u32<STRIDE>((unsigned int)k), hi = xor_lane_u32<STRIDE>((unsigned int)(k >> 32));
+  return ((u64)hi << 32) | lo;
+}
+
+template <int SIZE, int STRIDE>
+__device__ __forceinline__ void bitonic_merge(u64 &key, int lane) {
+  const u64 other = xor_lane_u64<STRIDE>(key);
+  const bool keep_min = ((lane & SIZE) == 0) == ((lane & STRIDE) == 0);
+  key = ((key < other) == keep_min) ? key : other;
+  if constexpr (STRIDE > 1) bitonic_merge<SIZE, STRIDE / 2>(key, lane);
+}
+
+// bitonic network over the first P lanes of a wave (P a compile-time power of two: fully unrolled, the direction
+// of every compare-exchange folds into constant lane masks)
+template <int P, int SIZE = 2>
+__device__ __forceinline__ void wave_bitonic_sort(u64 &key, int lane) {
+  bitonic_merge<SIZE, SIZE / 2>(key, lane);
+  if constexpr (SIZE < P) wave_bitonic_sort<P, SIZE * 2>(key, lane);
+}
+
+template <int P>
+__device__ __forceinline__ u64 wave_bitonic(u64 key, int lane) {
+  wave_bitonic_sort<P>(key, lane);
+  return key;
+}
+
+constexpr int SORT64_SEGS = 8;  // consecutive segments per wave: their loads are in flight together
 __global__ __launch_bounds__(64 * SORT64_WPB) void segment_sort64_kernel(u64 *__restrict__ keys,
                                                                           const u64 *__restrict__ offsets, int nq,
                                                                           unsigned int *__restrict__ counters,
                                                                           int by_index, int *__restrict__ idx_out,
                                                                           float *__restrict__ d2_out) {
   // idx_out != null: the sorted keys of the segments handled here go straight to the idx / d2 arrays
-  // (same offsets); the longer segments are split by split_long_kernel after their own sort
+  // (same offsets); the longer segments are split by split_long_kernel after their own sort.
+  // A wave takes SORT64_SEGS consecutive segments: one coalesced load of their offsets, all key loads issued
+  // before the first sort (with one segment per wave the kernel was bound by wave turnover latency).
   const int lane = threadIdx.x & 63;
-  const int seg = blockIdx.x * SORT64_WPB + (threadIdx.x >> 6);
-  if (seg >= nq) return;
-  const u64 a = offsets[seg], b = offsets[seg + 1];
-  const u64 len64 = b - a;
-  if (len64 == 0) return;
-  if (len64 > 64) {
-    if (lane == 0) {
-      atomicAdd(&counters[0], 1u);
-      if (len64 > (u64)SEG_MAX) atomicAdd(&counters[1], 1u);
+  const int seg0 = (blockIdx.x * SORT64_WPB + (threadIdx.x >> 6)) * SORT64_SEGS;
+  if (seg0 >= nq) return;
+  const int nseg = min(SORT64_SEGS, nq - seg0);
+  const u64 my_off = lane <= nseg ? offsets[seg0 + lane] : 0;
+  u64 a[SORT64_SEGS], key[SORT64_SEGS];
+  int len[SORT64_SEGS];
+  unsigned int n_gt64 = 0, n_gtmax = 0;
+#pragma unroll
+  for (int j = 0; j < SORT64_SEGS; ++j) {
+    const u64 lo = __shfl(my_off, j), hi = __shfl(my_off, j + 1);
+    a[j] = lo;
+    const u64 l64 = j < nseg ? hi - lo : 0;
+    if (l64 > 64) {
+      ++n_gt64;
+      if (l64 > (u64)SEG_MAX) ++n_gtmax;
     }
-    return;
+    len[j] = l64 > 64 ? 0 : (int)l64;  // longer segments are left to the other paths
+    key[j] = lane < len[j] ? keys[lo + lane] : ~0ull;
   }
-  const int len = (int)len64;
-  u64 key = lane < len ? keys[a + lane] : ~0ull;
-  int P = 2;
-  while (P < len) P <<= 1;  // wave-uniform: stages beyond the padded length are skipped
-  for (int size = 2; size <= P; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      const u64 other = __shfl_xor(key, stride);
-      const bool up = (lane & size) == 0;
-      const bool lower = (lane & stride) == 0;
-      const u64 mn = key < other ? key : other, mx = key < other ? other : key;
-      key = (lower == up) ? mn : mx;
-    }
+  if (lane == 0) {
+    if (n_gt64) atomicAdd(&counters[0], n_gt64);
+    if (n_gtmax) atomicAdd(&counters[1], n_gtmax);
   }
-  if (lane < len) {
-    if (idx_out) {
-      const unsigned int hi = (unsigned int)(key >> 32), lo = (unsigned int)key;
-      idx_out[a + lane] = (int)(by_index ? hi : lo);
-      d2_out[a + lane] = __uint_as_float(by_index ? lo : hi);
-    } else {
-      keys[a + lane] = key;
+#pragma unroll
+  for (int j = 0; j < SORT64_SEGS; ++j) {
+    const int ln = len[j];  // wave-uniform
+    if (ln == 0) continue;
+    u64 k = key[j];
+    // wave-uniform dispatch on the padded length: stages beyond it are never run
+    if (ln > 32) k = wave_bitonic<64>(k, lane);
+    else if (ln > 16) k = wave_bitonic<32>(k, lane);
+    else if (ln > 8) k = wave_bitonic<16>(k, lane);
+    else if (ln > 1) k = wave_bitonic<8>(k, lane);
+    if (lane < ln) {
+      if (idx_out) {
+        const unsigned int hi = (unsigned int)(k >> 32), lo = (unsigned int)k;
+        idx_out[a[j] + lane] = (int)(by_index ? hi : lo);
+        d2_out[a[j] + lane] = __uint_as_float(by_index ? lo : hi);
+      } else {
+        keys[a[j] + lane] = k;
+      }
     }
   }
 }
@@ -272,7 +326,8 @@ int sort_segments(Workspace *w, u64 *keys, u64 *alt, const u64 *d_offsets, size_
   *sorted_in = keys;
   if (total == 0) return PCLMI_OK;
   PCLMI_HIP(hipMemsetAsync(d_nlong, 0, 2 * sizeof(unsigned int), s));
-  hipLaunchKernelGGL(segment_sort64_kernel, dim3((unsigned)((nq + SORT64_WPB - 1) / SORT64_WPB)),
+  hipLaunchKernelGGL(segment_sort64_kernel,
+                     dim3((unsigned)((nq + SORT64_WPB * SORT64_SEGS - 1) / (SORT64_WPB * SORT64_SEGS))),
                      dim3(64 * SORT64_WPB), 0, s, keys, d_offsets, (int)nq, d_nlong, by_index, idx_out, d2_out);
   unsigned int cnts[2] = {0, 0};  // segments longer than 64 / longer than SEG_MAX
   PCLMI_HIP(hipMemcpyAsync(cnts, d_nlong, sizeof(cnts), hipMemcpyDeviceToHost, s));
