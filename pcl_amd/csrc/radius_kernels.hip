@@ -5,15 +5,16 @@
 // (strict), optionally only the nearest max_nn, ascending by (d2, index) when sorted, by index
 // otherwise.  The output is variable length, so the search runs as
 //   1. count pass   - the wave-uniform union traversal of traverse.hpp, every lane counting the hits
-//                     of its own query;
+//                     of its own query AND (without max_nn) keeping its first 64 keys
+//                     (d2 bits << 32 | index, or index << 32 | d2 bits for unsorted output) in a
+//                     fixed-pitch provisional row;
 //   2. exclusive scan of the counts -> CSR offsets (the only host synchronisation: the total);
-//   3. fill pass    - the same traversal again, every lane appending 64-bit keys
-//                     (d2 bits << 32 | index, or index << 32 | d2 bits for unsorted output) to its
-//                     own segment;
-//   4. per-segment sort of the keys (up to 64 entries: one wave, one key per lane, bitonic network
-//                     through cross-lane shuffles; up to 1024: bitonic network in LDS;
-//                     hipcub::DeviceSegmentedSort for the rare longer ones);
-//   5. split of the keys into the idx / d2 arrays (and truncation to max_nn).
+//   3a. no query with more than 64 hits (the common case): the provisional rows are sorted straight into
+//                     the CSR idx / d2 arrays (one key per lane, bitonic network with DPP exchanges) - done;
+//   3b. otherwise: fill pass - the same traversal again, every lane appending its keys to its own CSR
+//                     segment; per-segment sort (up to 64 entries as in 3a; up to 1024: bitonic network in
+//                     LDS; hipcub::DeviceSegmentedSort for the rare longer ones); split of the keys into the
+//                     idx / d2 arrays (and truncation to max_nn).
 // Queries are visited in Morton-cell order like the kNN path; segments are laid out in the caller's
 // query order.
 #include <hipcub/hipcub.hpp>
@@ -29,14 +30,21 @@ typedef unsigned long long u64;
 
 constexpr int R_WPB = 4;
 
-template <bool FILL>
+// MODE 0: count only.  MODE 1: fill - append keys to the CSR segment of the query (offsets known).
+// MODE 2: count AND write the first PROV_CAP keys of every query to its fixed-pitch provisional row
+// keys[qi * PROV_CAP ..]; *n_over counts the queries with more hits than that.  When none overflows (the common
+// case: ~32 neighbours), the rows are sorted straight into the CSR output and the second traversal is skipped.
+constexpr int PROV_CAP = 64;
+template <int MODE>
 __global__ __launch_bounds__(64 * R_WPB) void radius_union_kernel(TreeView t, const float *__restrict__ q,
                                                                    int q_stride_f,
                                                                    const int *__restrict__ order, int nq,
                                                                    float r2, float tau_r, int by_index,
                                                                    unsigned int *__restrict__ counts,
                                                                    const u64 *__restrict__ offsets,
-                                                                   u64 *__restrict__ keys) {
+                                                                   u64 *__restrict__ keys,
+                                                                   unsigned int *__restrict__ n_over) {
+  constexpr bool FILL = MODE == 1;
   const int lane = threadIdx.x & 63;
   LaneQuery lq;
   if (!load_lane_query<R_WPB>(q, q_stride_f, order, nq, lq)) return;
@@ -47,6 +55,7 @@ __global__ __launch_bounds__(64 * R_WPB) void radius_union_kernel(TreeView t, co
   unsigned int cnt = 0;
   u64 *out = nullptr;
   if (FILL && lq.alive) out = keys + offsets[lq.qi];
+  if (MODE == 2 && lq.alive) out = keys + (size_t)lq.qi * PROV_CAP;
 
   LaneStack st{0, 0, lane};
   st.push(1);
@@ -79,7 +88,7 @@ __global__ __launch_bounds__(64 * R_WPB) void radius_union_kernel(TreeView t, co
         for (int j = 0; j < 4; ++j) {
           // padded slots sit at 3e38: their d2 is +inf and never < r2; NaN queries never pass
           if (dd[j] < r2) {
-            if (FILL) {
+            if (FILL || (MODE == 2 && cnt < (unsigned int)PROV_CAP)) {
               const unsigned int ib = __float_as_uint(grp[g][12 + j]), db = __float_as_uint(dd[j]);
               out[cnt] = by_index ? (((u64)ib << 32) | db) : (((u64)db << 32) | ib);
             }
@@ -92,6 +101,10 @@ __global__ __launch_bounds__(64 * R_WPB) void radius_union_kernel(TreeView t, co
     }
   }
   if (!FILL && lq.alive) counts[lq.qi] = cnt;
+  if (MODE == 2) {
+    const int over = __popcll(__ballot(cnt > (unsigned int)PROV_CAP));
+    if (over && lane == 0) atomicAdd(n_over, (unsigned int)over);
+  }
 }
 
 // ---- per-segment sort ------------------------------------------------------------------------
@@ -231,6 +244,43 @@ __global__ __launch_bounds__(64 * SORT64_WPB) void segment_sort64_kernel(u64 *__
       } else {
         keys[a[j] + lane] = k;
       }
+    }
+  }
+}
+
+// Provisional rows (radius_union_kernel MODE 2, no query over PROV_CAP) -> sorted CSR idx / d2.
+__global__ __launch_bounds__(64 * SORT64_WPB) void prov_sort_kernel(const u64 *__restrict__ prov,
+                                                                     const unsigned int *__restrict__ counts,
+                                                                     const u64 *__restrict__ offsets, int nq,
+                                                                     int by_index, int *__restrict__ idx_out,
+                                                                     float *__restrict__ d2_out) {
+  const int lane = threadIdx.x & 63;
+  const int seg0 = (blockIdx.x * SORT64_WPB + (threadIdx.x >> 6)) * SORT64_SEGS;
+  if (seg0 >= nq) return;
+  const int nseg = min(SORT64_SEGS, nq - seg0);
+  const u64 my_off = lane < nseg ? offsets[seg0 + lane] : 0;
+  const unsigned int my_cnt = lane < nseg ? counts[seg0 + lane] : 0u;
+  u64 a[SORT64_SEGS], key[SORT64_SEGS];
+  int len[SORT64_SEGS];
+#pragma unroll
+  for (int j = 0; j < SORT64_SEGS; ++j) {
+    a[j] = __shfl(my_off, j);
+    len[j] = (int)__shfl((int)my_cnt, j);
+    key[j] = lane < len[j] ? prov[(size_t)(seg0 + j) * PROV_CAP + lane] : ~0ull;
+  }
+#pragma unroll
+  for (int j = 0; j < SORT64_SEGS; ++j) {
+    const int ln = len[j];  // wave-uniform
+    if (ln == 0) continue;
+    u64 k = key[j];
+    if (ln > 32) k = wave_bitonic<64>(k, lane);
+    else if (ln > 16) k = wave_bitonic<32>(k, lane);
+    else if (ln > 8) k = wave_bitonic<16>(k, lane);
+    else if (ln > 1) k = wave_bitonic<8>(k, lane);
+    if (lane < ln) {
+      const unsigned int hi = (unsigned int)(k >> 32), lo = (unsigned int)k;
+      idx_out[a[j] + lane] = (int)(by_index ? hi : lo);
+      d2_out[a[j] + lane] = __uint_as_float(by_index ? lo : hi);
     }
   }
 }
@@ -385,8 +435,9 @@ int radius_search_dev(const pclmi_tree *t, Workspace *w, const float *d_q, size_
   const int32_t *order = nullptr;
   int rc = launch_morton_order(t, w, d_q, nq, qsf, nullptr, nullptr, s, &order);
   if (rc) return rc;
-  // buf[0]: counts[nq + 1] (u32) | segment-length counters[2] (u32) | full offsets[nq + 1] (u64, only with max_nn)
-  const size_t counts_bytes = ((nq + 3) * sizeof(unsigned int) + 15) & ~(size_t)15;
+  // buf[0]: counts[nq + 1] (u32) | segment-length counters[2] + overflow counter (u32) | full offsets[nq + 1]
+  // (u64, only with max_nn)
+  const size_t counts_bytes = ((nq + 4) * sizeof(unsigned int) + 15) & ~(size_t)15;
   rc = w->ensure_buf(0, counts_bytes + (nq + 1) * sizeof(u64));
   if (rc) return rc;
   unsigned int *d_counts = (unsigned int *)w->buf[0];
@@ -397,19 +448,62 @@ int radius_search_dev(const pclmi_tree *t, Workspace *w, const float *d_q, size_
   const int by_index = (!sorted && !max_nn) ? 1 : 0;
   const unsigned waves = (unsigned)((nq + 63) / 64);
   const unsigned blocks = ((waves + R_WPB - 1) / R_WPB + 7) & ~7u;
+  // One traversal when it can be enough: count and keep the first PROV_CAP keys of every query in a fixed-pitch
+  // row; if no query has more, the rows are sorted into the output and the fill traversal never runs.
+  unsigned int *d_nover = d_nlong + 2;
+  const bool try_prov = !max_nn && nq * (size_t)PROV_CAP * sizeof(u64) <= ((size_t)2 << 30);
+  u64 *prov = nullptr;
+  if (try_prov) {
+    // buf[1] (the CSR key arrays of the two-traversal path) doubles as the provisional rows: only one of the
+    // two layouts is alive at a time (buf[3] is the scan's temporary storage and runs in between)
+    rc = w->ensure_buf(1, nq * (size_t)PROV_CAP * sizeof(u64));
+    if (rc) return rc;
+    prov = (u64 *)w->buf[1];
+  }
   {
     TimingScope ts(PCLMI_TIMER_RADIUS, s);
-    hipLaunchKernelGGL((radius_union_kernel<false>), dim3(blocks), dim3(64 * R_WPB), 0, s, t->view(), d_q, (int)qsf,
-                       order, (int)nq, r2, tau_r, by_index, d_counts, (const u64 *)nullptr, (u64 *)nullptr);
+    if (try_prov)
+      hipLaunchKernelGGL((radius_union_kernel<2>), dim3(blocks), dim3(64 * R_WPB), 0, s, t->view(), d_q, (int)qsf,
+                         order, (int)nq, r2, tau_r, by_index, d_counts, (const u64 *)nullptr, prov, d_nover);
+    else
+      hipLaunchKernelGGL((radius_union_kernel<0>), dim3(blocks), dim3(64 * R_WPB), 0, s, t->view(), d_q, (int)qsf,
+                         order, (int)nq, r2, tau_r, by_index, d_counts, (const u64 *)nullptr, (u64 *)nullptr,
+                         (unsigned int *)nullptr);
   }
   rc = scan_counts(w, d_counts, nq, d_off_full, s);
   if (rc) return rc;
   u64 total = 0;
+  unsigned int n_over = 0;
   PCLMI_HIP(hipMemcpyAsync(&total, d_off_full + nq, sizeof(u64), hipMemcpyDeviceToHost, s));
+  PCLMI_HIP(hipMemcpyAsync(&n_over, d_nover, sizeof(n_over), hipMemcpyDeviceToHost, s));
   PCLMI_HIP(hipStreamSynchronize(s));
   if (total == 0) {
     if (max_nn) PCLMI_HIP(hipMemsetAsync(d_offsets, 0, (nq + 1) * sizeof(uint64_t), s));
     PCLMI_HIP(hipStreamSynchronize(s));
+    return PCLMI_OK;
+  }
+  if (try_prov && n_over == 0) {
+    int32_t *pi = (int32_t *)dev_cache_get(total * sizeof(int32_t));
+    float *pd = (float *)dev_cache_get(total * sizeof(float));
+    if (!pi || !pd) {
+      dev_cache_put(pi);
+      dev_cache_put(pd);
+      return PCLMI_ERR_OOM;
+    }
+    hipLaunchKernelGGL(prov_sort_kernel,
+                       dim3((unsigned)((nq + SORT64_WPB * SORT64_SEGS - 1) / (SORT64_WPB * SORT64_SEGS))),
+                       dim3(64 * SORT64_WPB), 0, s, (const u64 *)prov, (const unsigned int *)d_counts,
+                       (const u64 *)d_off_full, (int)nq, by_index, pi, pd);
+    hipError_t pe = hipGetLastError();
+    if (pe == hipSuccess) pe = hipStreamSynchronize(s);
+    if (pe != hipSuccess) {
+      dev_cache_put(pi);
+      dev_cache_put(pd);
+      return hip_fail(pe, "radius search", __FILE__, __LINE__);
+    }
+    *d_idx = pi;
+    *d_d2 = pd;
+    *total_out = total;
     return PCLMI_OK;
   }
   // buf[1]: keys[total] | alt[total]
@@ -418,8 +512,9 @@ int radius_search_dev(const pclmi_tree *t, Workspace *w, const float *d_q, size_
   u64 *keys = (u64 *)w->buf[1], *alt = keys + total;
   {
     TimingScope ts(PCLMI_TIMER_RADIUS, s);
-    hipLaunchKernelGGL((radius_union_kernel<true>), dim3(blocks), dim3(64 * R_WPB), 0, s, t->view(), d_q, (int)qsf,
-                       order, (int)nq, r2, tau_r, by_index, (unsigned int *)nullptr, (const u64 *)d_off_full, keys);
+    hipLaunchKernelGGL((radius_union_kernel<1>), dim3(blocks), dim3(64 * R_WPB), 0, s, t->view(), d_q, (int)qsf,
+                       order, (int)nq, r2, tau_r, by_index, (unsigned int *)nullptr, (const u64 *)d_off_full, keys,
+                       (unsigned int *)nullptr);
   }
   int32_t *oi = nullptr;
   float *od = nullptr;
