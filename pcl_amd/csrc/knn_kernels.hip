@@ -239,11 +239,27 @@ __global__ __launch_bounds__(64 * WPB) void knn_union_ix_kernel(TreeView t, cons
   if (lq.alive) {
     int *oi = out_idx + (size_t)lq.qi * k_out;
     float *od = out_d2 + (size_t)lq.qi * k_out;
+    // full rows on 16-byte boundaries (the usual case): 128-bit stores - a 4-byte store per neighbour makes every
+    // store instruction touch 64 different cache lines
+    const bool wide = K % 4 == 0 && k_out == K &&
+                      ((((unsigned long long)out_idx | (unsigned long long)out_d2) & 15ull) == 0ull);
+    if (wide) {
 #pragma unroll
-    for (int j = 0; j < K; ++j) {
-      if (j < k_out) {
-        oi[j] = (int)(unsigned int)(key[j] & 0xffffffffull);
-        od[j] = __uint_as_float((unsigned int)(key[j] >> 32));
+      for (int j = 0; j + 3 < K; j += 4) {
+        reinterpret_cast<int4 *>(oi)[j / 4] =
+            make_int4((int)(unsigned int)key[j], (int)(unsigned int)key[j + 1], (int)(unsigned int)key[j + 2],
+                      (int)(unsigned int)key[j + 3]);
+        reinterpret_cast<float4 *>(od)[j / 4] =
+            make_float4(__uint_as_float((unsigned int)(key[j] >> 32)), __uint_as_float((unsigned int)(key[j + 1] >> 32)),
+                        __uint_as_float((unsigned int)(key[j + 2] >> 32)), __uint_as_float((unsigned int)(key[j + 3] >> 32)));
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        if (j < k_out) {
+          oi[j] = (int)(unsigned int)(key[j] & 0xffffffffull);
+          od[j] = __uint_as_float((unsigned int)(key[j] >> 32));
+        }
       }
     }
   }
