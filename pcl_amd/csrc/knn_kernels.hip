@@ -468,6 +468,7 @@ int launch_morton_order(const pclmi_tree *t, Workspace *w, const float *d_q, siz
   while (((size_t)1 << lg) < nq) ++lg;
   int bits = ((lg - 2) / 3) * 3;
   bits = bits < 6 ? 6 : (bits > 24 ? 24 : bits);
+  if (const char *e = getenv("PCLMI_CELL_BITS")) bits = atoi(e);  // development override
   const size_t nbins = (size_t)1 << bits;
   int rc = w->ensure_queries(nq, nbins);
   if (rc) return rc;
