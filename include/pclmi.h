@@ -348,6 +348,22 @@ int pclmi_correspondences_normal_shooting(const pclmi_tree *target, const float 
                                           size_t n_indices, int k, double max_distance,
                                           pclmi_correspondence *out, size_t *n_out);
 
+/* Replaces CorrespondenceEstimationBackProjection::determineCorrespondences
+ * (registration/include/pcl/registration/impl/correspondence_estimation_backprojection.hpp:58-107):
+ * for every source point, among its k nearest target points (one batched search) the arg-min of
+ * nn_dists[min_index] * (2 - cos^2(source normal, neighbour normal)) evaluated exactly as the reference loop
+ * evaluates it - the weight multiplies the distance of the RUNNING arg-min, and the arg-min is carried over
+ * from one source point to the next (:71) - reproduced in parallel by a scan over function composition.
+ * The pair is dropped when the minimum exceeds max_distance; distance = squared point distance of the chosen
+ * neighbour.  tgt_normals: one row per row of the cloud the tree was built on.  k <= 32.  out has capacity
+ * n_src (or n_indices); pairs come in source order. */
+int pclmi_correspondences_back_projection(const pclmi_tree *target, const float *src, size_t n_src,
+                                          size_t stride_bytes, const float *src_normals,
+                                          size_t sn_stride_bytes, const float *tgt_normals, size_t n_tgt,
+                                          size_t tn_stride_bytes, const int32_t *src_indices,
+                                          size_t n_indices, int k, double max_distance,
+                                          pclmi_correspondence *out, size_t *n_out);
+
 #ifdef __cplusplus
 }
 #endif

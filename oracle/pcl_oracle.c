@@ -1474,3 +1474,39 @@ int64_t orc_correspondences_normal_shooting(const float *src, int64_t ns, int ss
   orc_tree_free(t);
   return cnt;
 }
+
+int64_t orc_correspondences_back_projection(const float *src, int64_t ns, int ss, const float *sn, int sns,
+                                            const float *tgt, int64_t nt, int ts, const float *tn, int tns, int k,
+                                            double max_distance, orc_corr *out) {
+  if (nt == 0 || k <= 0) return 0;
+  orc_tree *t = orc_tree_build(tgt, nt, ts, 15);
+  int ke = k > nt ? (int)nt : k;
+  int32_t *idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)ke);
+  float *d2 = (float *)malloc(sizeof(float) * (size_t)ke);
+  int64_t cnt = 0;
+  int min_index = 0; /* :71 - outside the loop over the points */
+  for (int64_t i = 0; i < ns; ++i) {
+    const float *p = src + (size_t)i * ss, *a = sn + (size_t)i * sns;
+    if (!isfinite(p[0]) || !isfinite(p[1]) || !isfinite(p[2])) continue;
+    int m = orc_tree_knn(t, p, 1, ss, k, idx, d2, 1);
+    float min_dist = FLT_MAX;
+    for (int j = 0; j < m; ++j) {
+      const float *b = tn + (size_t)idx[j] * tns;
+      const float cos_angle = (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];     /* :80-82 */
+      const float dist = d2[min_index] * (2.0f - cos_angle * cos_angle);      /* :84 */
+      if (dist < min_dist) {
+        min_dist = dist;
+        min_index = j;
+      }
+    }
+    if (min_dist > max_distance) continue; /* :91-92 */
+    out[cnt].index_query = (int32_t)i;
+    out[cnt].index_match = idx[min_index];
+    out[cnt].distance = d2[min_index];
+    ++cnt;
+  }
+  free(idx);
+  free(d2);
+  orc_tree_free(t);
+  return cnt;
+}

@@ -189,6 +189,17 @@ int64_t orc_correspondences_normal_shooting(const float *src, int64_t ns, int ss
                                             int64_t nt, int tstride, int k, double max_distance,
                                             orc_corr *out);
 
+/* CorrespondenceEstimationBackProjection::determineCorrespondences
+ * (registration/include/pcl/registration/impl/correspondence_estimation_backprojection.hpp:58-107), restated
+ * with its two quirks: the weight (2 - cos^2) multiplies nn_dists[min_index] - the distance of the RUNNING
+ * arg-min, not of neighbour j (:84) - and min_index is declared outside the loop over the source points and
+ * never reset (:71).  No reference test covers this class: parity unpinned (restatement only).
+ * out must hold ns entries; returns the count. */
+int64_t orc_correspondences_back_projection(const float *src, int64_t ns, int sstride, const float *sn,
+                                            int snstride, const float *tgt, int64_t nt, int tstride,
+                                            const float *tn, int tnstride, int k, double max_distance,
+                                            orc_corr *out);
+
 #ifdef __cplusplus
 }
 #endif

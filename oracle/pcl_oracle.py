@@ -104,6 +104,9 @@ def lib():
         L.orc_correspondences_normal_shooting.restype = c_i64
         L.orc_correspondences_normal_shooting.argtypes = [c_f32p, c_i64, C.c_int, c_f32p, C.c_int, c_f32p, c_i64,
                                                           C.c_int, C.c_int, C.c_double, C.c_void_p]
+        L.orc_correspondences_back_projection.restype = c_i64
+        L.orc_correspondences_back_projection.argtypes = [c_f32p, c_i64, C.c_int, c_f32p, C.c_int, c_f32p, c_i64,
+                                                          C.c_int, c_f32p, C.c_int, C.c_int, C.c_double, C.c_void_p]
         L.orc_point_normal.restype = C.c_int
         L.orc_point_normal.argtypes = [c_f32p, C.c_int, c_i32p, c_i64, c_f32p, c_f32p]
         L.orc_normals.restype = C.c_int
@@ -211,6 +214,16 @@ def correspondences_normal_shooting(src, src_normals, tgt, k=10, max_distance=fl
     n = lib().orc_correspondences_normal_shooting(_p(src, c_f32p), len(src), src.shape[1], _p(sn, c_f32p), sn.shape[1],
                                                   _p(tgt, c_f32p), len(tgt), tgt.shape[1], k, max_distance,
                                                   out.ctypes.data)
+    return out[:n]
+
+
+def correspondences_back_projection(src, src_normals, tgt, tgt_normals, k=10,
+                                    max_distance=float(np.finfo(np.float64).max)):
+    src, sn, tgt, tn = _f32(src), _f32(src_normals), _f32(tgt), _f32(tgt_normals)
+    out = np.zeros(len(src), CORR_DTYPE)
+    n = lib().orc_correspondences_back_projection(_p(src, c_f32p), len(src), src.shape[1], _p(sn, c_f32p), sn.shape[1],
+                                                  _p(tgt, c_f32p), len(tgt), tgt.shape[1], _p(tn, c_f32p), tn.shape[1],
+                                                  k, max_distance, out.ctypes.data)
     return out[:n]
 
 

@@ -112,6 +112,10 @@ SIGNATURES = {
     "pclmi_correspondences_normal_shooting": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p,
                                                         C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_double,
                                                         C.c_void_p, C.POINTER(C.c_size_t)]),
+    "pclmi_correspondences_back_projection": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p,
+                                                        C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p,
+                                                        C.c_size_t, C.c_int, C.c_double, C.c_void_p,
+                                                        C.POINTER(C.c_size_t)]),
     "pclmi_icp_set_criteria": (C.c_int, [C.c_void_p, C.POINTER(IcpParams)]),
     "pclmi_icp_solve_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "pclmi_icp_run_dev": (C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_void_p]),
@@ -279,6 +283,20 @@ def correspondences_normal_shooting(target_tree, src, src_normals, k=10,
     n = C.c_size_t(0)
     _check(load_library().pclmi_correspondences_normal_shooting(
         target_tree.h, s.ctypes.data, len(s), s.shape[1] * 4, sn.ctypes.data, sn.shape[1] * 4,
+        None if ii is None else ii.ctypes.data, 0 if ii is None else len(ii), int(k), float(max_distance),
+        out.ctypes.data, C.byref(n)))
+    return out[:n.value]
+
+
+def correspondences_back_projection(target_tree, src, src_normals, tgt_normals, k=10,
+                                    max_distance=float(np.finfo(np.float64).max), src_indices=None):
+    s, sn, tn = _pts(src), _pts(src_normals), _pts(tgt_normals)
+    ii = None if src_indices is None else np.ascontiguousarray(src_indices, np.int32)
+    out = np.zeros(len(s) if ii is None else len(ii), CORR_DTYPE)
+    n = C.c_size_t(0)
+    _check(load_library().pclmi_correspondences_back_projection(
+        target_tree.h, s.ctypes.data, len(s), s.shape[1] * 4, sn.ctypes.data, sn.shape[1] * 4,
+        tn.ctypes.data, len(tn), tn.shape[1] * 4,
         None if ii is None else ii.ctypes.data, 0 if ii is None else len(ii), int(k), float(max_distance),
         out.ctypes.data, C.byref(n)))
     return out[:n.value]

@@ -7,6 +7,8 @@
 //   * CorrespondenceEstimationNormalShooting::determineCorrespondences
 //     (impl/correspondence_estimation_normal_shooting.hpp:60-165): one batched k-NN launch, then one lane per
 //     source point picks the neighbour closest to the line along the source normal.
+#include <hipcub/hipcub.hpp>
+
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -121,6 +123,111 @@ __global__ __launch_bounds__(256) void normal_shoot_kernel(const float4 *__restr
   dist[i] = best_d2;
 }
 
+// ---- CorrespondenceEstimationBackProjection --------------------------------------------------------------
+// The reference loop (impl/correspondence_estimation_backprojection.hpp:58-107) weighs neighbour j by
+// nn_dists[min_index] * (2 - cos^2), where min_index is the running arg-min - and is NOT reset between source
+// points (:71), so point i starts from the arg-min point i-1 ended with.  That serial chain carries one small
+// integer, so it parallelises as a scan over function composition: every point gets the map
+// "min_index on entry -> min_index on exit" (k entries), an exclusive scan composes the maps in source order,
+// and entry 0 of the scanned map is the state each point really starts from.
+struct BpMap {
+  unsigned long long w[4];  // 32 entries of 8 bits
+};
+__host__ __device__ inline unsigned bp_get(const BpMap &a, unsigned i) {
+  const unsigned long long x = i < 8 ? a.w[0] : i < 16 ? a.w[1] : i < 24 ? a.w[2] : a.w[3];
+  return (unsigned)(x >> ((i & 7u) * 8u)) & 0xffu;
+}
+__host__ __device__ inline void bp_set(BpMap &a, unsigned i, unsigned v) {
+  const unsigned long long m = (unsigned long long)(v & 0xffu) << ((i & 7u) * 8u);
+  if (i < 8) a.w[0] |= m;
+  else if (i < 16) a.w[1] |= m;
+  else if (i < 24) a.w[2] |= m;
+  else a.w[3] |= m;
+}
+__host__ __device__ inline BpMap bp_identity() {
+  BpMap r;
+  r.w[0] = 0x0706050403020100ull;
+  r.w[1] = 0x0f0e0d0c0b0a0908ull;
+  r.w[2] = 0x1716151413121110ull;
+  r.w[3] = 0x1f1e1d1c1b1a1918ull;
+  return r;
+}
+struct BpCompose {  // (a then b)
+  __host__ __device__ BpMap operator()(const BpMap &a, const BpMap &b) const {
+    BpMap r;
+    r.w[0] = r.w[1] = r.w[2] = r.w[3] = 0ull;
+    for (unsigned s = 0; s < 32; ++s) bp_set(r, s, bp_get(b, bp_get(a, s)));
+    return r;
+  }
+};
+
+// weight[i][j] = 2 - cos^2 of the angle between source normal i and the normal of its j-th neighbour (:80-83)
+__global__ __launch_bounds__(256) void bp_weight_kernel(const float4 *__restrict__ sn, const float4 *__restrict__ tn,
+                                                        const int *__restrict__ idx, size_t total, int k,
+                                                        float *__restrict__ weight) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int t = idx[e];
+  float w = __builtin_nanf("");
+  if (t >= 0) {
+    const float4 a = sn[e / (size_t)k], b = tn[t];
+    const float c = __fadd_rn(__fadd_rn(__fmul_rn(a.x, b.x), __fmul_rn(a.y, b.y)), __fmul_rn(a.z, b.z));
+    w = __fsub_rn(2.0f, __fmul_rn(c, c));
+  }
+  weight[e] = w;
+}
+
+// the reference's inner loop for one point, entered with min_index = s
+__device__ __forceinline__ int bp_walk(const float *__restrict__ d2, const float *__restrict__ w, int k, int s,
+                                       float &min_dist) {
+  min_dist = 3.402823466e+38f;
+  int mi = s;
+  for (int j = 0; j < k; ++j) {
+    const float dist = __fmul_rn(d2[mi], w[j]);
+    if (dist < min_dist) {
+      min_dist = dist;
+      mi = j;
+    }
+  }
+  return mi;
+}
+
+__global__ __launch_bounds__(256) void bp_map_kernel(const int *__restrict__ idx, const float *__restrict__ d2,
+                                                     const float *__restrict__ weight, int n, int k,
+                                                     BpMap *__restrict__ maps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  BpMap m = bp_identity();
+  if (idx[(size_t)i * k] >= 0) {  // searchable point (others leave the state alone)
+    m.w[0] = m.w[1] = m.w[2] = m.w[3] = 0ull;
+    float md;
+    for (int s = 0; s < 32; ++s)
+      bp_set(m, s, s < k ? (unsigned)bp_walk(d2 + (size_t)i * k, weight + (size_t)i * k, k, s, md) : (unsigned)s);
+  }
+  maps[i] = m;
+}
+
+__global__ __launch_bounds__(256) void bp_pick_kernel(const int *__restrict__ idx, const float *__restrict__ d2,
+                                                      const float *__restrict__ weight,
+                                                      const BpMap *__restrict__ entry, int n, int k,
+                                                      double max_distance, int *__restrict__ match,
+                                                      float *__restrict__ dist) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int best = -1;
+  float best_d2 = 0.f;
+  if (idx[(size_t)i * k] >= 0) {
+    float md;
+    const int mi = bp_walk(d2 + (size_t)i * k, weight + (size_t)i * k, k, (int)bp_get(entry[i], 0), md);
+    if (!((double)md > max_distance)) {  // :91-92
+      best = idx[(size_t)i * k + mi];
+      best_d2 = d2[(size_t)i * k + mi];
+    }
+  }
+  match[i] = best;
+  dist[i] = best_d2;
+}
+
 // host rows (strided, optionally through an index list) -> device float4
 int upload_rows(const float *h, size_t n_rows, size_t stride_bytes, const int32_t *rows, size_t n, DevBuf<float4> &out) {
   std::vector<float4> tmp(n ? n : 1);
@@ -210,6 +317,75 @@ int pclmi_correspondences_normal_shooting(const pclmi_tree *target, const float 
                      (const float4 *)target->d_cloud, idx.p, d2.p, (int)n, k_eff, max_distance, match.p, dist.p);
   PCLMI_HIP(hipGetLastError());
   PCLMI_HIP(hipStreamSynchronize(target->stream));
+  std::vector<int> hm(n);
+  std::vector<float> hd(n);
+  PCLMI_HIP(hipMemcpy(hm.data(), match.p, n * 4, hipMemcpyDeviceToHost));
+  PCLMI_HIP(hipMemcpy(hd.data(), dist.p, n * 4, hipMemcpyDeviceToHost));
+  size_t c = 0;
+  for (size_t i = 0; i < n; ++i) {
+    if (hm[i] < 0) continue;
+    out[c].index_query = src_indices ? src_indices[i] : (int32_t)i;
+    out[c].index_match = hm[i];
+    out[c].distance = hd[i];
+    ++c;
+  }
+  *n_out = c;
+  return PCLMI_OK;
+}
+
+int pclmi_correspondences_back_projection(const pclmi_tree *target, const float *src, size_t n_src,
+                                          size_t stride_bytes, const float *src_normals, size_t sn_stride_bytes,
+                                          const float *tgt_normals, size_t n_tgt, size_t tn_stride_bytes,
+                                          const int32_t *src_indices, size_t n_indices, int k, double max_distance,
+                                          pclmi_correspondence *out, size_t *n_out) {
+  PCLMI_CHECK(target && n_out, PCLMI_ERR_INVALID, "NULL argument");
+  *n_out = 0;
+  PCLMI_CHECK(n_src == 0 || (src && src_normals && out), PCLMI_ERR_INVALID, "NULL argument");
+  PCLMI_CHECK(n_tgt == 0 || tgt_normals, PCLMI_ERR_INVALID, "tgt_normals is NULL");
+  auto ok_stride = [](size_t s) { return s >= 12 && s % 4 == 0; };
+  PCLMI_CHECK(ok_stride(stride_bytes) && ok_stride(sn_stride_bytes) && ok_stride(tn_stride_bytes), PCLMI_ERR_INVALID,
+              "bad stride");
+  PCLMI_CHECK(k > 0, PCLMI_ERR_INVALID, "k must be positive (got %d)", k);
+  PCLMI_CHECK(pclmi_device_count() > 0, PCLMI_ERR_NO_DEVICE, "no HIP device visible: libpclmi has no CPU fallback");
+  const size_t n = src_indices ? n_indices : n_src;
+  if (n == 0 || target->n == 0) return PCLMI_OK;
+  PCLMI_CHECK(n < ((size_t)1 << 31), PCLMI_ERR_UNSUPPORTED, "more than 2^31-1 source points");
+  // the tree hands out rows of the cloud it was built on: the normals must cover every one of them
+  PCLMI_CHECK(n_tgt >= target->rows, PCLMI_ERR_INVALID, "%zu target normals for a target cloud of %zu rows", n_tgt,
+              (size_t)target->rows);
+  const int k_eff = (size_t)k > target->n ? (int)target->n : k;
+  PCLMI_CHECK(k_eff <= 32, PCLMI_ERR_UNSUPPORTED, "back projection supports k <= 32 (got %d)", k_eff);
+  PCLMI_HIP(hipSetDevice(target->device));
+  hipStream_t s = target->stream;
+  DevBuf<float4> ds, dn, dtn;
+  RC(upload_rows(src, n_src, stride_bytes, src_indices, n, ds));
+  RC(upload_rows(src_normals, n_src, sn_stride_bytes, src_indices, n, dn));
+  RC(upload_rows(tgt_normals, n_tgt, tn_stride_bytes, nullptr, n_tgt, dtn));
+  DevBuf<int> idx, match;
+  DevBuf<float> d2, weight, dist;
+  DevBuf<BpMap> maps, entry;
+  const size_t total = n * (size_t)k_eff;
+  RC(idx.alloc(total));
+  RC(d2.alloc(total));
+  RC(weight.alloc(total));
+  RC(match.alloc(n));
+  RC(dist.alloc(n));
+  RC(maps.alloc(n));
+  RC(entry.alloc(n));
+  RC(pclmi_knn_dev(target, (const float *)ds.p, n, 16, k_eff, idx.p, d2.p, nullptr));
+  hipLaunchKernelGGL(bp_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dn.p, dtn.p, idx.p, total,
+                     k_eff, weight.p);
+  const unsigned grid = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(bp_map_kernel, dim3(grid), dim3(256), 0, s, idx.p, d2.p, weight.p, (int)n, k_eff, maps.p);
+  size_t tmp_bytes = 0;
+  PCLMI_HIP(hipcub::DeviceScan::ExclusiveScan(nullptr, tmp_bytes, maps.p, entry.p, BpCompose(), bp_identity(), (int)n, s));
+  DevBuf<unsigned char> tmp;
+  RC(tmp.alloc(tmp_bytes ? tmp_bytes : 1));
+  PCLMI_HIP(hipcub::DeviceScan::ExclusiveScan(tmp.p, tmp_bytes, maps.p, entry.p, BpCompose(), bp_identity(), (int)n, s));
+  hipLaunchKernelGGL(bp_pick_kernel, dim3(grid), dim3(256), 0, s, idx.p, d2.p, weight.p, entry.p, (int)n, k_eff,
+                     max_distance, match.p, dist.p);
+  PCLMI_HIP(hipGetLastError());
+  PCLMI_HIP(hipStreamSynchronize(s));
   std::vector<int> hm(n);
   std::vector<float> hd(n);
   PCLMI_HIP(hipMemcpy(hm.data(), match.p, n * 4, hipMemcpyDeviceToHost));

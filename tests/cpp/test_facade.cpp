@@ -15,6 +15,7 @@
 #include <pcl/common/time.h>
 #include <pcl/common/transforms.h>
 #include <pcl/features/normal_3d.h>
+#include <pcl/kdtree/io.h>
 #include <pcl/kdtree/kdtree_flann.h>
 #include <pcl/point_types.h>
 #include <pcl/registration/correspondence_estimation.h>
@@ -24,6 +25,7 @@
 #include <pcl/registration/correspondence_rejection_sample_consensus.h>
 #include <pcl/registration/correspondence_rejection_trimmed.h>
 #include <pcl/registration/correspondence_rejection_var_trimmed.h>
+#include <pcl/registration/correspondence_estimation_backprojection.h>
 #include <pcl/registration/correspondence_estimation_normal_shooting.h>
 #include <pcl/registration/icp.h>
 #include <pcl/registration/transformation_estimation_point_to_plane_lls.h>
@@ -432,6 +434,67 @@ TEST(CorrespondenceEstimationNormalShooting_parallel_planes) {
   for (unsigned int i = 0; i < corr->size(); i++) EXPECT_EQ((*corr)[i].index_query, (*corr)[i].index_match);
 }
 
+// ---- CorrespondenceEstimationBackProjection (no reference test exists; API + k = 1 degenerates to 1-NN) ----
+TEST(CorrespondenceEstimationBackProjection_api) {
+  PointCloud<PointXYZ>::Ptr source = cloud_source.makeShared(), target = cloud_target.makeShared();
+  search::KdTree<PointXYZ>::Ptr tree(new search::KdTree<PointXYZ>());
+  PointCloud<Normal>::Ptr sn(new PointCloud<Normal>), tn(new PointCloud<Normal>);
+  NormalEstimation<PointXYZ, Normal> ne;
+  ne.setSearchMethod(tree);
+  ne.setKSearch(8);
+  ne.setInputCloud(source);
+  ne.compute(*sn);
+  ne.setInputCloud(target);
+  ne.compute(*tn);
+  registration::CorrespondenceEstimationBackProjection<PointXYZ, PointXYZ, Normal> ce;
+  Correspondences none;
+  ce.setInputCloud(source);
+  ce.setInputTarget(target);
+  ce.determineCorrespondences(none);  // normals missing: warns and returns nothing (:46-50)
+  EXPECT_EQ(none.size(), size_t(0));
+  ce.setSourceNormals(sn);
+  ce.setTargetNormals(tn);
+  KdTreeFLANN<PointXYZ> ref;
+  ref.setInputCloud(target);
+  std::vector<int> idx;
+  std::vector<float> d2;
+  Correspondences c1, c10;
+  ce.setKSearch(1);
+  ce.determineCorrespondences(c1);
+  EXPECT_EQ(c1.size(), source->size());
+  for (size_t i = 0; i < c1.size(); ++i) {
+    ref.nearestKSearch(source->points[i], 1, idx, d2);
+    EXPECT_EQ(c1[i].index_query, int(i));
+    EXPECT_EQ(c1[i].index_match, idx[0]);
+    EXPECT(c1[i].distance == d2[0]);
+  }
+  ce.setKSearch(10);
+  ce.determineCorrespondences(c10);
+  EXPECT_EQ(c10.size(), source->size());
+  for (size_t i = 0; i < c10.size(); ++i) {  // the match is one of the 10 nearest, with its own distance
+    ref.nearestKSearch(source->points[i], 10, idx, d2);
+    bool found = false;
+    for (size_t j = 0; j < idx.size(); ++j) found |= idx[j] == c10[i].index_match && d2[j] == c10[i].distance;
+    EXPECT(found);
+  }
+}
+
+// ---- kdtree/include/pcl/kdtree/impl/io.hpp:47-84 ---------------------------------------------------
+TEST(getApproximateIndices_equals_per_point_search) {
+  PointCloud<PointXYZ>::Ptr source = cloud_source.makeShared(), target = cloud_target.makeShared();
+  std::vector<int> indices;
+  getApproximateIndices<PointXYZ>(source, target, indices);
+  EXPECT_EQ(indices.size(), source->size());
+  KdTreeFLANN<PointXYZ> ref;
+  ref.setInputCloud(target);
+  std::vector<int> idx;
+  std::vector<float> d2;
+  for (size_t i = 0; i < indices.size(); ++i) {
+    ref.nearestKSearch(*source, int(i), 1, idx, d2);
+    EXPECT_EQ(indices[i], idx[0]);
+  }
+}
+
 // ---- test/registration/test_registration_api.cpp ---------------------------------------------------
 static bool pairsEqual(const Correspondences &c, const std::vector<double> &gold, bool check_query) {
   if (c.size() * 2 != gold.size()) return false;
@@ -589,6 +652,8 @@ int main(int argc, char **argv) {
   RUN(NormalEstimation_bun0);
   RUN(TransformationEstimationPointToPlaneLLS_known_motion);
   RUN(CorrespondenceEstimationNormalShooting_parallel_planes);
+  RUN(CorrespondenceEstimationBackProjection_api);
+  RUN(getApproximateIndices_equals_per_point_search);
   RUN(RegistrationAPI);
   RUN(IterativeClosestPointGolden);
   std::printf("%d checks, %d failed\n", g_checks, g_fail);

@@ -131,3 +131,51 @@ def test_normal_shooting_reference_planes_and_oracle(capi, orc):
     small = capi.Tree(tgt[:6])
     g = capi.correspondences_normal_shooting(small, src[:50], sn[:50], k=10)
     assert np.array_equal(g, orc.correspondences_normal_shooting(src[:50], sn[:50], tgt[:6], 10))
+
+
+def test_back_projection_vs_oracle(capi, orc):
+    """CorrespondenceEstimationBackProjection (impl/correspondence_estimation_backprojection.hpp:58-107): no reference
+    test covers it (parity unpinned), so the bar is the oracle's restatement - including the arg-min the reference
+    carries from one source point to the next - bit-exact, through the scan over function composition."""
+    rng = np.random.default_rng(31)
+    tgt = util.uniform_cloud(20_000, 7, 0, 10)
+    src = util.uniform_cloud(5_000, 8, 0, 10)
+
+    def unit(n):
+        v = rng.normal(size=(n, 3)).astype(np.float32)
+        return (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+
+    sn, tn = unit(len(src)), unit(len(tgt))
+    tt = capi.Tree(tgt)
+    for k, md in ((10, float(np.finfo(np.float64).max)), (4, 0.05), (32, 0.3), (1, 1.0)):
+        g = capi.correspondences_back_projection(tt, src, sn, tn, k=k, max_distance=md)
+        o = orc.correspondences_back_projection(src, sn, tgt, tn, k, md)
+        assert np.array_equal(g, o), (k, md)
+        assert md >= 1.0 or 0 < len(g) < len(src)
+    # the carried arg-min matters: scrambling the source order changes pairs of the SAME source points
+    g = capi.correspondences_back_projection(tt, src, sn, tn, k=10)
+    perm = rng.permutation(len(src))
+    gp = capi.correspondences_back_projection(tt, src[perm], sn[perm], tn, k=10)
+    back = np.empty(len(src), np.int64)
+    back[perm] = np.arange(len(src))
+    assert len(g) == len(gp) == len(src)
+    assert (g["index_match"] != gp["index_match"][back]).any(), "the order-dependence of the reference loop is gone"
+    assert np.array_equal(gp, orc.correspondences_back_projection(src[perm], sn[perm], tgt, tn, 10))
+    # index view = the reference loop over indices_ (state carried along the VIEW), non-finite source rows skipped
+    view = np.arange(0, 5000, 7, dtype=np.int32)
+    g = capi.correspondences_back_projection(tt, src, sn, tn, k=10, src_indices=view)
+    o = orc.correspondences_back_projection(src[view], sn[view], tgt, tn, 10)
+    o["index_query"] = view[o["index_query"]]
+    assert np.array_equal(g, o)
+    bad = src.copy()
+    bad[5::50, 1] = np.nan
+    g = capi.correspondences_back_projection(tt, bad, sn, tn, k=10)
+    assert np.array_equal(g, orc.correspondences_back_projection(bad, sn, tgt, tn, 10)) and len(g) == len(src) - 100
+    # k larger than the cloud is clamped; k > 32 is refused; missing target normals are refused
+    small = capi.Tree(tgt[:6])
+    g = capi.correspondences_back_projection(small, src[:50], sn[:50], tn[:6], k=10)
+    assert np.array_equal(g, orc.correspondences_back_projection(src[:50], sn[:50], tgt[:6], tn[:6], 10))
+    with pytest.raises(capi.PclmiError):
+        capi.correspondences_back_projection(tt, src, sn, tn, k=33)
+    with pytest.raises(capi.PclmiError):
+        capi.correspondences_back_projection(tt, src, sn, tn[:100], k=10)
