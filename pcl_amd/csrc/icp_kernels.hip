@@ -96,20 +96,34 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[NV], double (*l
   }
 }
 
-// wave sum of N doubles (lanes with use == false contribute zero) -> row[0..N) by lane 0
-template <int N>
-__device__ __forceinline__ void wave_reduce_to_row(double (&v)[N], bool use, double *row, int lane) {
+// wave sum of 8 doubles (lanes with use == false contribute zero) -> row[0..8).  Reduce-scatter butterfly: at
+// the exchanges over 32, 16 and 8 lanes every lane hands HALF of its values to its partner and keeps the other
+// half (8 -> 4 -> 2 -> 1 values per lane), then the one value left goes through the last three exchanges: 10
+// 64-bit shuffles per lane instead of 48 for eight independent butterflies.  The order of the additions is fixed
+// by the lane numbers, so the sums are reproducible bit for bit.
+__device__ __forceinline__ void wave_reduce_to_row(double (&v)[8], bool use, double *row, int lane) {
+  double x[8];
 #pragma unroll
-  for (int j = 0; j < N; ++j) {
-    double x = use ? v[j] : 0.0;
+  for (int j = 0; j < 8; ++j) x[j] = use ? v[j] : 0.0;
+  const bool h32 = (lane & 32) != 0, h16 = (lane & 16) != 0, h8 = (lane & 8) != 0;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
-    v[j] = x;
+  for (int j = 0; j < 4; ++j) {  // lanes 0-31 go on with values 0-3, lanes 32-63 with values 4-7
+    const double send = h32 ? x[j] : x[j + 4], keep = h32 ? x[j + 4] : x[j];
+    x[j] = keep + __shfl_xor(send, 32);
   }
-  if (lane == 0) {
 #pragma unroll
-    for (int j = 0; j < N; ++j) row[j] = v[j];
+  for (int j = 0; j < 2; ++j) {
+    const double send = h16 ? x[j] : x[j + 2], keep = h16 ? x[j + 2] : x[j];
+    x[j] = keep + __shfl_xor(send, 16);
   }
+  {
+    const double send = h8 ? x[0] : x[1], keep = h8 ? x[1] : x[0];
+    x[0] = keep + __shfl_xor(send, 8);
+  }
+#pragma unroll
+  for (int o = 4; o > 0; o >>= 1) x[0] += __shfl_xor(x[0], o);
+  // the lane whose low three bits are zero holds the total of value 4 * bit5 + 2 * bit4 + bit3
+  if ((lane & 7) == 0) row[(lane >> 3) & 7] = x[0];
 }
 
 constexpr int NS = PCLMI_ICP_NSUMS;  // 24
@@ -198,15 +212,15 @@ __global__ __launch_bounds__(64 * ICP_WPB) __attribute__((amdgpu_waves_per_eu(8,
   const double one_p = paired ? 1.0 : 0.0, one_c = counted ? 1.0 : 0.0;
   {
     double v[8] = {one_p, sx, sy, sz, tx, ty, tz, sx * tx};
-    wave_reduce_to_row<8>(v, paired, &lds[wib][0], lane);
+    wave_reduce_to_row(v, paired, &lds[wib][0], lane);
   }
   {
     double v[8] = {sx * ty, sx * tz, sy * tx, sy * ty, sy * tz, sz * tx, sz * ty, sz * tz};
-    wave_reduce_to_row<8>(v, paired, &lds[wib][8], lane);
+    wave_reduce_to_row(v, paired, &lds[wib][8], lane);
   }
   {
     double v[8] = {(double)dc, (double)dc - (double)prev, one_c, ox, oy, oz, 0.0, 0.0};
-    wave_reduce_to_row<8>(v, counted, &lds[wib][16], lane);
+    wave_reduce_to_row(v, counted, &lds[wib][16], lane);
   }
   __syncthreads();
   if (threadIdx.x < NS) {
