@@ -92,6 +92,20 @@ def pmc_traffic(which="knn16"):
     return best
 
 
+def pmc_valu_issue(which, kernel_ms, n_simd=1024, clock_ghz=2.4):
+    """Fraction of the launch's VALU issue slots the kernel used: SQ_INSTS_VALU of the committed PMC summary x 4
+    cycles per wave64 instruction / (SIMDs x kernel cycles at the 2.4 GHz peak engine clock).  None without a summary."""
+    import glob
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*%s*_pmc.json" % which))):
+        try:
+            v = json.load(open(p)).get("SQ_INSTS_VALU")
+            if v:
+                return 4.0 * v / (n_simd * kernel_ms * 1e-3 * clock_ghz * 1e9)
+        except Exception:
+            pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -130,6 +144,9 @@ def main():
     capi.load_library().pclmi_set_device(local)
 
     verbose = rehearsal or os.environ.get("PCLMI_BENCH_VERBOSE") == "1"
+    if verbose:  # a stuck rank says where: stack dump after PCLMI_BENCH_WATCHDOG seconds (default 150), then exit
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ.get("PCLMI_BENCH_WATCHDOG", "150")), exit=True)
 
     def log(msg):
         if verbose:
@@ -220,7 +237,10 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "knn_union_ix_kernel<16,40,1>", "kernel_ms": kern_ms, "launches": int(k_n),
                      "algorithmic_bytes_per_launch": algo_bytes,
-                     "order_ms": o_ms / max(o_n, 1)},
+                     "order_ms": o_ms / max(o_n, 1),
+                     # the traversal is VALU-issue-bound, not HBM-bound: the binding resource beside
+                     # the nominal HBM fraction
+                     "valu_issue_frac": pmc_valu_issue("knn16", kern_ms)},
     }
 
     # ---- ICP iterations / s (configs[3]) -------------------------------------------------------
