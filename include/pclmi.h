@@ -64,7 +64,10 @@ int pclmi_set_device(int device);
  * radius count+fill passes, the fused ICP step) with HIP events recorded on the stream the
  * kernel is launched on.  pclmi_timing_read waits for the recorded events, adds their
  * durations to the timer and returns total milliseconds and launch count (reset != 0 zeroes
- * the timer afterwards).  Off by default; costs two event records per call when on. */
+ * the timer afterwards).  Off by default; costs two event records per bracketed launch when on
+ * (a few microseconds each).  pclmi_timing_enable(0) off, (1) every timer, (PCLMI_TIMER_BIT(t) | ...)
+ * only the timers named. */
+#define PCLMI_TIMER_BIT(t) (2 << (t))
 #define PCLMI_TIMER_KNN 0
 #define PCLMI_TIMER_RADIUS 1
 #define PCLMI_TIMER_ICP_STEP 2

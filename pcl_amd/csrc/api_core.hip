@@ -44,7 +44,8 @@ std::atomic<int> g_timing{0};
 }  // namespace
 
 TimingScope::TimingScope(int which, hipStream_t stream) : s(stream) {
-  if (!g_timing.load(std::memory_order_relaxed)) return;
+  const int mask = g_timing.load(std::memory_order_relaxed);
+  if (!mask || (mask != 1 && !(mask & (2 << which)))) return;  // 1: every timer; else bit (2 << timer)
   TimingRec *r = new TimingRec{which, nullptr, nullptr};
   if (hipEventCreate(&r->a) != hipSuccess || hipEventCreate(&r->b) != hipSuccess ||
       hipEventRecord(r->a, s) != hipSuccess) {
@@ -265,7 +266,7 @@ int pclmi_set_device(int device) {
 }
 
 int pclmi_timing_enable(int on) {
-  g_timing.store(on ? 1 : 0);
+  g_timing.store(on < 0 ? 0 : on);
   return PCLMI_OK;
 }
 

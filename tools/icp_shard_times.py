@@ -22,14 +22,14 @@ src_all = tgt[rng.permutation(n)] + rng.normal(0, 0.1, (n, 3)).astype(np.float32
 Ti = np.linalg.inv(T0)
 src_all = (src_all.astype(np.float64) @ Ti[:3, :3].T + Ti[:3, 3]).astype(np.float32)
 tree = capi.Tree(tgt)
-for world in (1, 2, 4, 8):
+for world in [int(v) for v in os.environ.get("WORLDS", "1,2,4,8").split(",")]:
     per = (n + world - 1) // world
     src = src_all[:per]
     best = None
     for rep in range(3):
         ctx = capi.IcpShard(tree, src)
         torch.cuda.synchronize()
-        capi.timing_enable(True)
+        capi.timing_enable(os.environ.get("NO_EVENTS") != "1")
         capi.timing_read(capi.TIMER_ICP_STEP, reset=True)
         t0 = time.perf_counter()
         ctx.run_dev(25.0, iters)
