@@ -295,7 +295,8 @@ int pclmi_icp_begin(const pclmi_tree *target, const float *src, size_t n_src, si
   return PCLMI_OK;
 }
 
-int pclmi_icp_step_dev(pclmi_icp_ctx *c, double max_correspondence_distance, double *d_sums, void *stream) {
+static int icp_step_enqueue(pclmi_icp_ctx *c, double max_correspondence_distance, double *d_sums, void *stream,
+                            bool fuse_solve) {
   PCLMI_CHECK(c && d_sums, PCLMI_ERR_INVALID, "NULL argument");
   PCLMI_HIP(hipSetDevice(c->tree->device));
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
@@ -303,11 +304,15 @@ int pclmi_icp_step_dev(pclmi_icp_ctx *c, double max_correspondence_distance, dou
   const double thr2 = max_correspondence_distance * max_correspondence_distance;  // icp.hpp:57
   c->last_thr2 = thr2;
   launch_icp_step(c->tree, c->pts.p, c->n, c->pending, make_xf(c->T), thr2, c->nn.p, c->nn_slot.p, c->dist.p, c->origin,
-                  c->partials.p, d_sums, s, c->dev_mode ? c->state.p : nullptr, c->stepped);
+                  c->partials.p, d_sums, s, c->dev_mode ? c->state.p : nullptr, c->stepped, fuse_solve);
   c->pending = false;
   c->stepped = true;
   PCLMI_HIP(hipGetLastError());
   return PCLMI_OK;
+}
+
+int pclmi_icp_step_dev(pclmi_icp_ctx *c, double max_correspondence_distance, double *d_sums, void *stream) {
+  return icp_step_enqueue(c, max_correspondence_distance, d_sums, stream, false);
 }
 
 int pclmi_icp_step(pclmi_icp_ctx *c, double max_correspondence_distance, double h_sums[PCLMI_ICP_NSUMS]) {
@@ -349,10 +354,13 @@ int pclmi_icp_solve_dev(pclmi_icp_ctx *c, const double *d_sums, void *stream) {
 
 int pclmi_icp_run_dev(pclmi_icp_ctx *c, double max_correspondence_distance, int iterations, void *stream) {
   PCLMI_CHECK(c, PCLMI_ERR_INVALID, "NULL argument");
-  for (int i = 0; i < iterations; ++i) {
-    RC(pclmi_icp_step_dev(c, max_correspondence_distance, c->sums.p, stream));
-    RC(pclmi_icp_solve_dev(c, c->sums.p, stream));
-  }
+  PCLMI_CHECK(!c->pending, PCLMI_ERR_INVALID,
+              "pclmi_icp_run_dev after pclmi_icp_set_transform: one context is driven either from the host or "
+              "from the device");
+  // single-GPU loop: nothing sits between the reduction and the solve, so they share one launch
+  // (reduce_solve_kernel); per iteration: step kernel -> reduce + solve
+  c->dev_mode = true;
+  for (int i = 0; i < iterations; ++i) RC(icp_step_enqueue(c, max_correspondence_distance, c->sums.p, stream, true));
   return PCLMI_OK;
 }
 

@@ -227,14 +227,31 @@ __global__ __launch_bounds__(64 * ICP_WPB) __attribute__((amdgpu_waves_per_eu(8,
     double s = 0.0;
 #pragma unroll
     for (int w = 0; w < ICP_WPB; ++w) s += lds[w][threadIdx.x];
-    partials[(size_t)blockIdx.x * NS + threadIdx.x] = s;
+    // column-major (sum j of block b at [j * blocks + b]): the reduction pass reads each column as one contiguous run
+    partials[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = s;
   }
 }
 
-// fixed-order sum of the block partials: block j of the grid produces out[j]
+// fixed-order sum of one column of block partials by one workgroup of 256: element r of column j sits at
+// partials[r * row_stride + j * col_stride]
+__device__ __forceinline__ double column_sum(const double *__restrict__ partials, int nrows, size_t row_stride,
+                                             size_t col_stride, int j, double *sh) {
+  double s = 0.0;
+  for (int r = threadIdx.x; r < nrows; r += 256) s += partials[(size_t)r * row_stride + (size_t)j * col_stride];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  return sh[0];
+}
+
+// block j of the grid produces out[j]
 // st (nullable): the step before this pass has consumed the pending transform of the device state
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const double *__restrict__ partials, int nrows,
-                                                              int nv, double *__restrict__ out,
+                                                              size_t row_stride, size_t col_stride,
+                                                              double *__restrict__ out,
                                                               IcpDevState *__restrict__ st = nullptr) {
   __shared__ double sh[256];
   const int j = blockIdx.x;
@@ -242,21 +259,13 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double *__re
     if (st->done) return;  // block-uniform
     if (j == 0 && threadIdx.x == 0) st->apply = 0;
   }
-  double s = 0.0;
-  for (int r = threadIdx.x; r < nrows; r += 256) s += partials[(size_t)r * nv + j];
-  sh[threadIdx.x] = s;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) out[j] = sh[0];
+  const double s = column_sum(partials, nrows, row_stride, col_stride, j, sh);
+  if (threadIdx.x == 0) out[j] = s;
 }
 
 // One lane turns the (all-reduced) sums into the next transform and evaluates the convergence criteria
 // (icp.hpp:103-108,171-196): the device-side twin of the loop body of pclmi_icp_align.
-__global__ __launch_bounds__(64) void icp_solve_kernel(const double *__restrict__ sums, IcpDevState *__restrict__ st) {
-  if (threadIdx.x != 0 || st->done) return;
+__device__ __forceinline__ void icp_solve_body(const double *__restrict__ sums, IcpDevState *__restrict__ st) {
   double h[NS];
 #pragma unroll
   for (int j = 0; j < NS; ++j) h[j] = sums[j];
@@ -296,6 +305,39 @@ __global__ __launch_bounds__(64) void icp_solve_kernel(const double *__restrict_
       fabs(fit) <= st->euclidean_fitness_epsilon) {  // icp.hpp:193-196
     st->converged = 1;
     st->done = 1;
+  }
+}
+
+__global__ __launch_bounds__(64) void icp_solve_kernel(const double *__restrict__ sums, IcpDevState *__restrict__ st) {
+  if (threadIdx.x != 0 || st->done) return;
+  icp_solve_body(sums, st);
+}
+
+// Single-GPU loop: nothing sits between the column sums and the solve, so they share ONE launch - the block that
+// finishes last (a ticket counter in the device state) runs the solve on the sums the others have published.
+__global__ __launch_bounds__(256) void reduce_solve_kernel(const double *__restrict__ partials, int nrows,
+                                                           size_t row_stride, size_t col_stride,
+                                                           double *__restrict__ out, IcpDevState *__restrict__ st) {
+  __shared__ double sh[256];
+  __shared__ int is_last;
+  const int j = blockIdx.x;
+  if (st->done) return;  // block-uniform: `done` only changes in the solve, after every block has passed here
+  const double s = column_sum(partials, nrows, row_stride, col_stride, j, sh);
+  if (threadIdx.x == 0) {
+    out[j] = s;
+    __threadfence();  // publish out[j] device-wide before taking a ticket
+    const unsigned int t = atomicAdd(&st->ticket, 1u);
+    is_last = (t == gridDim.x - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (is_last && threadIdx.x == 0) {
+    __threadfence();  // acquire: the other blocks' sums
+    st->ticket = 0;   // ready for the next iteration's launch
+    st->apply = 0;    // the step before this pass has consumed the pending transform
+    double h[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) h[i] = __hip_atomic_load(&out[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    icp_solve_body(h, st);
   }
 }
 
@@ -496,7 +538,7 @@ unsigned icp_step_blocks(size_t n) {
 
 void launch_icp_step(const pclmi_tree *t, float4 *d_pts, size_t n, bool apply, const Xf &T, double thr2,
                      int *d_nn, int *d_nn_slot, float *d_dist, const double origin[3], double *d_partials,
-                     double *d_sums, hipStream_t s, IcpDevState *st, bool have_prev) {
+                     double *d_sums, hipStream_t s, IcpDevState *st, bool have_prev, bool fuse_solve) {
   const unsigned blocks = icp_step_blocks(n);
   const int levels = nn1_per_lane() ? lane_nearest_levels(t->M) : 0;
   {
@@ -511,7 +553,13 @@ void launch_icp_step(const pclmi_tree *t, float4 *d_pts, size_t n, bool apply, c
                          apply ? 1 : 0, T, (float)thr2, thr2, d_nn, d_nn_slot, d_dist, origin[0], origin[1], origin[2],
                          d_partials, (const IcpDevState *)st, 0, 0);
   }
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(NS), dim3(256), 0, s, d_partials, (int)blocks, NS, d_sums, st);
+  // the step kernel writes its partials column-major: row stride 1, column stride = blocks
+  if (fuse_solve && st)
+    hipLaunchKernelGGL(reduce_solve_kernel, dim3(NS), dim3(256), 0, s, d_partials, (int)blocks, (size_t)1, (size_t)blocks,
+                       d_sums, st);
+  else
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(NS), dim3(256), 0, s, d_partials, (int)blocks, (size_t)1,
+                       (size_t)blocks, d_sums, st);
 }
 
 unsigned pair_reduce_blocks(size_t n) {
@@ -525,16 +573,16 @@ void launch_pair_reduce(const float4 *src, const int *sidx, const float4 *tgt, c
   const unsigned blocks = pair_reduce_blocks(n);
   hipLaunchKernelGGL(pair_reduce_kernel, dim3(blocks), dim3(64 * PR_WPB), 0, s, src, sidx, tgt, tidx, flags, (int)n,
                      origin[0], origin[1], origin[2], d_partials);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(NS), dim3(256), 0, s, d_partials, (int)blocks, NS, d_sums,
-                     (IcpDevState *)nullptr);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(NS), dim3(256), 0, s, d_partials, (int)blocks, (size_t)NS, (size_t)1,
+                     d_sums, (IcpDevState *)nullptr);
 }
 
 void launch_moment_reduce(const float4 *src, const int *sidx, size_t n, double *d_partials, double *d_sums,
                           hipStream_t s) {
   const unsigned blocks = pair_reduce_blocks(n);
   hipLaunchKernelGGL(moment_reduce_kernel, dim3(blocks), dim3(64 * PR_WPB), 0, s, src, sidx, (int)n, d_partials);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(NS), dim3(256), 0, s, d_partials, (int)blocks, NS, d_sums,
-                     (IcpDevState *)nullptr);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(NS), dim3(256), 0, s, d_partials, (int)blocks, (size_t)NS, (size_t)1,
+                     d_sums, (IcpDevState *)nullptr);
 }
 
 void launch_count_within(const float4 *src, const int *sidx, const float4 *tgt, const int *tidx, size_t n,

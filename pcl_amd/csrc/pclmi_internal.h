@@ -192,6 +192,7 @@ struct IcpDevState {
   int max_iterations, min_correspondences;
   double fit, tdelta;
   double transformation_epsilon, euclidean_fitness_epsilon;
+  unsigned int ticket;  // blocks of reduce_solve_kernel that have published their sum (0 between launches)
 };
 void launch_transform(float4 *d_pts, size_t n, const Xf &T, hipStream_t s);
 void launch_transform_pending(float4 *d_pts, size_t n, IcpDevState *st, hipStream_t s);  // applies st->T iff st->apply
@@ -203,7 +204,8 @@ unsigned icp_step_blocks(size_t n);
 // st (nullable): take the pending transform from the device-side state instead of apply / T
 void launch_icp_step(const pclmi_tree *t, float4 *d_pts, size_t n, bool apply, const Xf &T, double thr2,
                      int *d_nn, int *d_nn_slot, float *d_dist, const double origin[3], double *d_partials,
-                     double *d_sums, hipStream_t s, IcpDevState *st = nullptr, bool have_prev = false);
+                     double *d_sums, hipStream_t s, IcpDevState *st = nullptr, bool have_prev = false,
+                     bool fuse_solve = false);  // fuse_solve (needs st): the solve runs in the reduction's launch
 // development switch (environment PCLMI_NN1=union): 1-NN searches use the wave-uniform traversal instead of
 // the per-lane one
 bool nn1_per_lane();
