@@ -93,16 +93,18 @@ def icp_align_gpu_sharded(target_tree, src_shard, params, guess=None, group=None
     return rc, T, aligned, it, ok, pairs
 
 
-def icp_align_gpu_sharded_dev(target_tree, src_shard, params, guess=None, group=None, check_every=8):
+def icp_align_gpu_sharded_dev(target_tree, src_shard, params, guess=None, group=None, check_every=8,
+                              force_collective=False):
     """Device-resident variant of icp_align_gpu_sharded: same results, one host sync per `check_every`
-    iterations.  Runs on torch's current stream (the collective is ordered on it too)."""
+    iterations.  Runs on torch's current stream (the collective is ordered on it too).
+    force_collective: issue the all-reduce even in a group of one rank (tests: RCCL between the library's kernels)."""
     import torch
     import torch.distributed as dist
     ctx = capi.IcpShard(target_tree, src_shard, guess)
     ctx.set_criteria(params)
     dev = torch.device("cuda", torch.cuda.current_device())
     sums = torch.zeros(capi.ICP_NSUMS, dtype=torch.float64, device=dev)
-    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    multi = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force_collective)
     cur = torch.cuda.current_stream()
     own = None
     if not cur.cuda_stream:

@@ -296,3 +296,17 @@ def test_device_resident_loop_equals_host_driven_loop(capi, orc):
     with pytest.raises(capi.PclmiError):
         ctx.set_transform(np.eye(4, dtype=np.float32))
     ctx.end(want_aligned=False)
+
+
+def test_rccl_all_reduce_between_the_library_kernels():
+    """tests/rccl_single_rank.py in a process of its own: a one-rank nccl (= RCCL) process group, the sharded
+    device-resident driver and bench.py's N > 1 loop shape with the all-reduce issued between the library's step and
+    solve kernels, equal to pclmi_icp_align bit for bit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "rccl_single_rank.py"), "29655"],
+                       capture_output=True, text=True, timeout=110)
+    print(r.stdout[-2000:], r.stderr[-3000:])
+    assert r.returncode == 0 and "RCCL single-rank loop OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
