@@ -453,6 +453,96 @@ __global__ void cell_scatter_kernel(const unsigned int *__restrict__ cell, const
   order[offs[cell[i]] + rank[i]] = i;
 }
 
+
+// ---- two-level counting sort (the default for large batches) ------------------------------------------------------
+// cell_count_kernel above pays one device-wide returning atomic per query (43 us per 1M queries: they are resolved
+// beyond the XCD's L2).  Here the cell number is split into a high and a low part and every counter lives in LDS:
+//   1. tile_count_kernel: one workgroup per tile of the batch; LDS histogram of the HIGH part, the returning LDS
+//      atomic is the query's rank inside (tile, high bin); the tile's histogram goes to tilehist[bin][tile];
+//   2. exclusive scan of tilehist (bin-major): start of every (bin, tile) run, hence of every high bin;
+//   3. tile_scatter_kernel: (low part, row) pairs to their high bin (order inside a bin: by tile, then rank);
+//   4. bin_sort_kernel: one workgroup per high bin counting-sorts its run by the LOW part in LDS (histogram, scan,
+//      returning LDS atomics for the position) and writes the row numbers to `order`.
+// Any bin size works (a workgroup loops over its run); the order inside a cell is arbitrary, as before.
+__device__ __forceinline__ unsigned int morton_cell(const float *p, float lox, float loy, float loz, float sx, float sy,
+                                                    float sz, int shift) {
+  float fx = (p[0] - lox) * sx, fy = (p[1] - loy) * sy, fz = (p[2] - loz) * sz;
+  unsigned int ix = (unsigned int)fminf(fmaxf(fx, 0.f), 1023.f);
+  unsigned int iy = (unsigned int)fminf(fmaxf(fy, 0.f), 1023.f);
+  unsigned int iz = (unsigned int)fminf(fmaxf(fz, 0.f), 1023.f);
+  return (spread10(ix) | (spread10(iy) << 1) | (spread10(iz) << 2)) >> shift;
+}
+
+constexpr int TILE_TPB = 1024;
+__global__ __launch_bounds__(TILE_TPB) void tile_count_kernel(const float *__restrict__ q, int q_stride_f, int nq, float lox,
+                                                              float loy, float loz, float sx, float sy, float sz, int shift,
+                                                              int lo_bits, int nb_hi, int tile_size, int ntiles,
+                                                              unsigned int *__restrict__ cell, unsigned int *__restrict__ rank,
+                                                              unsigned int *__restrict__ tilehist) {
+  extern __shared__ unsigned int lds_hist[];
+  for (int b = threadIdx.x; b < nb_hi; b += TILE_TPB) lds_hist[b] = 0u;
+  __syncthreads();
+  const int tile = blockIdx.x;
+  const long long begin = (long long)tile * tile_size;
+  const long long end = begin + tile_size < (long long)nq ? begin + tile_size : (long long)nq;
+  for (long long i = begin + threadIdx.x; i < end; i += TILE_TPB) {
+    const unsigned int c = morton_cell(q + (size_t)i * q_stride_f, lox, loy, loz, sx, sy, sz, shift);
+    cell[i] = c;
+    rank[i] = atomicAdd(&lds_hist[c >> lo_bits], 1u);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < nb_hi; b += TILE_TPB) tilehist[(size_t)b * ntiles + tile] = lds_hist[b];
+  if (tile == 0 && threadIdx.x == 0) tilehist[(size_t)nb_hi * ntiles] = 0u;  // the scan turns it into nq
+}
+
+__global__ void tile_scatter_kernel(const unsigned int *__restrict__ cell, const unsigned int *__restrict__ rank, int nq,
+                                    int lo_bits, int tile_size, int ntiles, const unsigned int *__restrict__ scanned,
+                                    uint2 *__restrict__ pairs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  const unsigned int c = cell[i];
+  const unsigned int pos = scanned[(size_t)(c >> lo_bits) * ntiles + i / tile_size] + rank[i];
+  pairs[pos] = make_uint2(c & ((1u << lo_bits) - 1u), (unsigned int)i);
+}
+
+constexpr int BIN_TPB = 256;
+__global__ __launch_bounds__(BIN_TPB) void bin_sort_kernel(const uint2 *__restrict__ pairs,
+                                                           const unsigned int *__restrict__ scanned, int ntiles,
+                                                           int nb_lo, int *__restrict__ order) {
+  extern __shared__ unsigned int lds_lo[];  // nb_lo counters, then BIN_TPB partial sums
+  unsigned int *part = lds_lo + nb_lo;
+  const unsigned int start = scanned[(size_t)blockIdx.x * ntiles], end = scanned[(size_t)(blockIdx.x + 1) * ntiles];
+  if (start == end) return;  // block-uniform
+  for (int b = threadIdx.x; b < nb_lo; b += BIN_TPB) lds_lo[b] = 0u;
+  __syncthreads();
+  for (unsigned int i = start + threadIdx.x; i < end; i += BIN_TPB) atomicAdd(&lds_lo[pairs[i].x], 1u);
+  __syncthreads();
+  // exclusive scan of the nb_lo counters: per-thread runs, Hillis-Steele over the BIN_TPB run totals
+  const int per = (nb_lo + BIN_TPB - 1) / BIN_TPB;
+  const int b0 = threadIdx.x * per;
+  unsigned int run = 0u;
+  for (int b = b0; b < b0 + per && b < nb_lo; ++b) run += lds_lo[b];
+  part[threadIdx.x] = run;
+  __syncthreads();
+  for (int o = 1; o < BIN_TPB; o <<= 1) {
+    const unsigned int add = threadIdx.x >= o ? part[threadIdx.x - o] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += add;
+    __syncthreads();
+  }
+  unsigned int base = part[threadIdx.x] - run;  // exclusive prefix of this thread's run
+  for (int b = b0; b < b0 + per && b < nb_lo; ++b) {
+    const unsigned int c = lds_lo[b];
+    lds_lo[b] = base;
+    base += c;
+  }
+  __syncthreads();
+  for (unsigned int i = start + threadIdx.x; i < end; i += BIN_TPB) {
+    const uint2 pr = pairs[i];
+    order[start + atomicAdd(&lds_lo[pr.x], 1u)] = (int)pr.y;
+  }
+}
+
 }  // namespace
 
 
@@ -470,16 +560,42 @@ int launch_morton_order(const pclmi_tree *t, Workspace *w, const float *d_q, siz
   bits = bits < 6 ? 6 : (bits > 24 ? 24 : bits);
   if (const char *e = getenv("PCLMI_CELL_BITS")) bits = atoi(e);  // development override
   const size_t nbins = (size_t)1 << bits;
-  int rc = w->ensure_queries(nq, nbins);
+  // large batches: the two-level counting sort with LDS counters (see tile_count_kernel)
+  static const bool atomic_order = [] {
+    const char *e = getenv("PCLMI_ORDER");  // development switch: PCLMI_ORDER=atomic keeps the one-level sort
+    return e && e[0] == 'a';
+  }();
+  const bool two_level = !stable && !atomic_order && nq >= 32768;
+  const int lo_bits = bits / 2, hi_bits = bits - lo_bits;
+  const int nb_hi = 1 << hi_bits, nb_lo = 1 << lo_bits;
+  int ntiles = (int)((nq + 4095) / 4096);
+  ntiles = ntiles > 512 ? 512 : ntiles;
+  const int tile_size = (int)((nq + ntiles - 1) / ntiles);
+  int rc = w->ensure_queries(nq, two_level ? (size_t)nb_hi * ntiles + 1 : nbins);
   if (rc) return rc;
+  if (two_level && (rc = w->ensure_scratch(nq * sizeof(uint2)))) return rc;
   float sc[3];
   for (int d = 0; d < 3; ++d) {
     float ext = bb_hi[d] - bb_lo[d];
     sc[d] = ext > 0.f ? 1024.f / ext : 0.f;
   }
   TimingScope ts(PCLMI_TIMER_ORDER, s);
-  PCLMI_HIP(hipMemsetAsync(w->hist, 0, nbins * sizeof(unsigned int), s));
   const unsigned grid = (unsigned)((nq + 255) / 256);
+  if (two_level) {
+    hipLaunchKernelGGL(tile_count_kernel, dim3(ntiles), dim3(TILE_TPB), (size_t)nb_hi * sizeof(unsigned int), s, d_q,
+                       (int)q_stride_f, (int)nq, bb_lo[0], bb_lo[1], bb_lo[2], sc[0], sc[1], sc[2], 30 - bits, lo_bits, nb_hi,
+                       tile_size, ntiles, w->keys_in, w->ranks, w->hist);
+    size_t tmp = w->cap_tmp;
+    PCLMI_HIP(hipcub::DeviceScan::ExclusiveSum(w->sort_tmp, tmp, w->hist, w->hist, nb_hi * ntiles + 1, s));
+    hipLaunchKernelGGL(tile_scatter_kernel, dim3(grid), dim3(256), 0, s, w->keys_in, w->ranks, (int)nq, lo_bits, tile_size,
+                       ntiles, w->hist, (uint2 *)w->scratch);
+    hipLaunchKernelGGL(bin_sort_kernel, dim3(nb_hi), dim3(BIN_TPB), (size_t)(nb_lo + BIN_TPB) * sizeof(unsigned int), s,
+                       (const uint2 *)w->scratch, w->hist, ntiles, nb_lo, w->vals_out);
+    PCLMI_HIP(hipGetLastError());
+    *d_order = w->vals_out;
+    return PCLMI_OK;
+  }
+  PCLMI_HIP(hipMemsetAsync(w->hist, 0, nbins * sizeof(unsigned int), s));
   hipLaunchKernelGGL(cell_count_kernel, dim3(grid), dim3(256), 0, s, d_q, (int)q_stride_f, (int)nq,
                      bb_lo[0], bb_lo[1], bb_lo[2], sc[0], sc[1], sc[2], 30 - bits, w->keys_in, w->ranks, w->hist);
   if (stable) {
