@@ -134,6 +134,36 @@ def test_large_vs_oracle_tree(capi, orc, n, nq, k):
     _check(capi, orc, pts, q, k, brute=False)
 
 
+def test_large_skewed_batches_through_the_two_level_query_order(capi, orc):
+    """Batches of >= 32768 queries take the two-level counting sort (knn_kernels.hip tile_count_kernel ...): every
+    query must come out exactly once whatever the distribution - all queries in one tiny corner (one high bin),
+    queries far outside the tree's box, non-finite rows, a batch size that is no multiple of the tile."""
+    pts = util.uniform_cloud(200_000, 51, 0, 1024)
+    tree, otree = capi.Tree(pts), orc.Tree(pts)
+    rng = np.random.default_rng(52)
+    corner = (rng.random((40_001, 3), dtype=np.float32) * 3 + 500).astype(np.float32)        # one cell or two
+    spread = (rng.random((50_000, 3), dtype=np.float32) * 3000 - 1000).astype(np.float32)     # mostly outside the box
+    mixed = np.concatenate([corner[:20_000], spread[:20_000], util.uniform_cloud(30_003, 53, 0, 1024)])
+    mixed[7] = np.nan
+    mixed[33_000, 2] = np.inf
+    for q in (corner, spread, mixed):
+        for k in (16, 1):
+            gi, gd = tree.knn(q, k)
+            good = np.isfinite(q).all(axis=1)
+            sel = np.flatnonzero(good)[:: max(1, good.sum() // 4000)]  # the oracle checks a sample ...
+            oi, od = otree.knn(q[sel], k, nthreads=8)
+            assert np.array_equal(gi[sel], oi) and np.array_equal(gd[sel].view(np.int32), od.view(np.int32))
+            assert (gi[~good] == -1).all() and np.isnan(gd[~good]).all()
+            # ... and every finite row was written: first neighbour recomputed from the coordinates
+            d = q[good] - pts[gi[good][:, 0]]
+            rec = ((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]).astype(np.float32)
+            assert np.array_equal(rec, gd[good][:, 0])
+    # radius search shares the ordering
+    ro, ri, rd = tree.radius(corner, 12.0)
+    oo, oi, od = otree.radius(corner[:2000], 12.0)
+    assert np.array_equal(ro[:2001], oo) and np.array_equal(ri[:oo[-1]], oi) and np.array_equal(rd[:oo[-1]], od)
+
+
 def test_surface_like_and_far_queries(capi, orc):
     rng = np.random.default_rng(9)
     # points on a few planes + noise (real clouds are 2-manifolds), queries partly far outside
