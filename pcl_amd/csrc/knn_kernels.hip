@@ -426,6 +426,54 @@ __device__ __forceinline__ unsigned int spread10(unsigned int v) {
   return v;
 }
 
+// 30-bit curve index of a 10-bit-per-axis grid cell; its top bits are the index of the coarser cell.
+// PCLMI_HILBERT: Hilbert curve (Skilling's axes-to-transpose) instead of the Z-order: consecutive cells are always
+// face neighbours, so the 64 consecutive queries of a wavefront never straddle one of the Z-order's long jumps.
+#ifndef PCLMI_HILBERT
+#define PCLMI_HILBERT 1
+#endif
+__device__ __forceinline__ unsigned int curve_index(unsigned int ix, unsigned int iy, unsigned int iz) {
+#if PCLMI_HILBERT
+  unsigned int X[3] = {ix, iy, iz};
+#pragma unroll
+  for (unsigned int Q = 512u; Q > 1u; Q >>= 1) {
+    const unsigned int P = Q - 1u;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (X[i] & Q) {
+        X[0] ^= P;
+      } else {
+        const unsigned int t = (X[0] ^ X[i]) & P;
+        X[0] ^= t;
+        X[i] ^= t;
+      }
+    }
+  }
+  X[1] ^= X[0];
+  X[2] ^= X[1];
+  unsigned int t = 0u;
+#pragma unroll
+  for (unsigned int Q = 512u; Q > 1u; Q >>= 1)
+    if (X[2] & Q) t ^= Q - 1u;
+  X[0] ^= t;
+  X[1] ^= t;
+  X[2] ^= t;
+  return (spread10(X[0]) << 2) | (spread10(X[1]) << 1) | spread10(X[2]);
+#else
+  return spread10(ix) | (spread10(iy) << 1) | (spread10(iz) << 2);
+#endif
+}
+
+__device__ __forceinline__ unsigned int morton_cell(const float *p, float lox, float loy, float loz, float sx, float sy,
+                                                    float sz, int shift) {
+  float fx = (p[0] - lox) * sx, fy = (p[1] - loy) * sy, fz = (p[2] - loz) * sz;
+  // NaN / out-of-box queries clamp into the grid; order only affects speed, never results
+  unsigned int ix = (unsigned int)fminf(fmaxf(fx, 0.f), 1023.f);
+  unsigned int iy = (unsigned int)fminf(fmaxf(fy, 0.f), 1023.f);
+  unsigned int iz = (unsigned int)fminf(fmaxf(fz, 0.f), 1023.f);
+  return curve_index(ix, iy, iz) >> shift;
+}
+
 // Query ordering = counting sort by Morton cell.  Only coherence matters (the order inside a
 // cell is irrelevant and results never depend on it), so one histogram pass, one scan and one
 // scatter pass replace a full radix sort.
@@ -435,13 +483,7 @@ __global__ void cell_count_kernel(const float *__restrict__ q, int q_stride_f, i
                                   unsigned int *__restrict__ hist) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nq) return;
-  const float *p = q + (size_t)i * q_stride_f;
-  float fx = (p[0] - lox) * sx, fy = (p[1] - loy) * sy, fz = (p[2] - loz) * sz;
-  // NaN / out-of-box queries clamp into the grid; order only affects speed, never results
-  unsigned int ix = (unsigned int)fminf(fmaxf(fx, 0.f), 1023.f);
-  unsigned int iy = (unsigned int)fminf(fmaxf(fy, 0.f), 1023.f);
-  unsigned int iz = (unsigned int)fminf(fmaxf(fz, 0.f), 1023.f);
-  unsigned int c = (spread10(ix) | (spread10(iy) << 1) | (spread10(iz) << 2)) >> shift;
+  const unsigned int c = morton_cell(q + (size_t)i * q_stride_f, lox, loy, loz, sx, sy, sz, shift);
   cell[i] = c;
   rank[i] = atomicAdd(&hist[c], 1u);  // position inside the cell: the scatter needs no second atomic
 }
@@ -464,15 +506,6 @@ __global__ void cell_scatter_kernel(const unsigned int *__restrict__ cell, const
 //   4. bin_sort_kernel: one workgroup per high bin counting-sorts its run by the LOW part in LDS (histogram, scan,
 //      returning LDS atomics for the position) and writes the row numbers to `order`.
 // Any bin size works (a workgroup loops over its run); the order inside a cell is arbitrary, as before.
-__device__ __forceinline__ unsigned int morton_cell(const float *p, float lox, float loy, float loz, float sx, float sy,
-                                                    float sz, int shift) {
-  float fx = (p[0] - lox) * sx, fy = (p[1] - loy) * sy, fz = (p[2] - loz) * sz;
-  unsigned int ix = (unsigned int)fminf(fmaxf(fx, 0.f), 1023.f);
-  unsigned int iy = (unsigned int)fminf(fmaxf(fy, 0.f), 1023.f);
-  unsigned int iz = (unsigned int)fminf(fmaxf(fz, 0.f), 1023.f);
-  return (spread10(ix) | (spread10(iy) << 1) | (spread10(iz) << 2)) >> shift;
-}
-
 constexpr int TILE_TPB = 1024;
 __global__ __launch_bounds__(TILE_TPB) void tile_count_kernel(const float *__restrict__ q, int q_stride_f, int nq, float lox,
                                                               float loy, float loz, float sx, float sy, float sz, int shift,
