@@ -249,12 +249,16 @@ __global__ __launch_bounds__(64 * SORT64_WPB) void segment_sort64_kernel(u64 *__
 }
 
 // Provisional rows (radius_union_kernel MODE 2, no query over PROV_CAP) -> sorted CSR idx / d2.
+// Two consecutive segments of at most 32 keys each (most of them, at ~31 neighbours per query) share one pass of
+// the 32-key network: the first in lanes 0-31, the second in lanes 32-63 - the network's last stage leaves the
+// upper half in DESCENDING order, so its lanes write mirrored.
 __global__ __launch_bounds__(64 * SORT64_WPB) void prov_sort_kernel(const u64 *__restrict__ prov,
                                                                      const unsigned int *__restrict__ counts,
                                                                      const u64 *__restrict__ offsets, int nq,
                                                                      int by_index, int *__restrict__ idx_out,
                                                                      float *__restrict__ d2_out) {
   const int lane = threadIdx.x & 63;
+  const int half = lane >> 5, l32 = lane & 31;
   const int seg0 = (blockIdx.x * SORT64_WPB + (threadIdx.x >> 6)) * SORT64_SEGS;
   if (seg0 >= nq) return;
   const int nseg = min(SORT64_SEGS, nq - seg0);
@@ -266,21 +270,45 @@ __global__ __launch_bounds__(64 * SORT64_WPB) void prov_sort_kernel(const u64 *_
   for (int j = 0; j < SORT64_SEGS; ++j) {
     a[j] = __shfl(my_off, j);
     len[j] = (int)__shfl((int)my_cnt, j);
-    key[j] = lane < len[j] ? prov[(size_t)(seg0 + j) * PROV_CAP + lane] : ~0ull;
   }
 #pragma unroll
-  for (int j = 0; j < SORT64_SEGS; ++j) {
-    const int ln = len[j];  // wave-uniform
-    if (ln == 0) continue;
-    u64 k = key[j];
-    if (ln > 32) k = wave_bitonic<64>(k, lane);
-    else if (ln > 16) k = wave_bitonic<32>(k, lane);
-    else if (ln > 8) k = wave_bitonic<16>(k, lane);
-    else if (ln > 1) k = wave_bitonic<8>(k, lane);
-    if (lane < ln) {
-      const unsigned int hi = (unsigned int)(k >> 32), lo = (unsigned int)k;
-      idx_out[a[j] + lane] = (int)(by_index ? hi : lo);
-      d2_out[a[j] + lane] = __uint_as_float(by_index ? lo : hi);
+  for (int j = 0; j < SORT64_SEGS; j += 2) {
+    if (len[j] <= 32 && len[j + 1] <= 32) {  // wave-uniform: the pair shares key[j]
+      const int myl = half ? len[j + 1] : len[j];
+      key[j] = l32 < myl ? prov[(size_t)(seg0 + j + half) * PROV_CAP + l32] : ~0ull;
+      key[j + 1] = ~0ull;
+    } else {
+      key[j] = lane < len[j] ? prov[(size_t)(seg0 + j) * PROV_CAP + lane] : ~0ull;
+      key[j + 1] = lane < len[j + 1] ? prov[(size_t)(seg0 + j + 1) * PROV_CAP + lane] : ~0ull;
+    }
+  }
+  auto emit = [&](u64 k, u64 base, int pos) {
+    const unsigned int hi = (unsigned int)(k >> 32), lo = (unsigned int)k;
+    idx_out[base + pos] = (int)(by_index ? hi : lo);
+    d2_out[base + pos] = __uint_as_float(by_index ? lo : hi);
+  };
+#pragma unroll
+  for (int j = 0; j < SORT64_SEGS; j += 2) {
+    if (len[j] <= 32 && len[j + 1] <= 32) {
+      const int mx = max(len[j], len[j + 1]);  // wave-uniform
+      if (mx == 0) continue;
+      u64 k = key[j];
+      if (mx > 1) k = wave_bitonic<32>(k, lane);  // lanes 0-31 ascending, lanes 32-63 descending
+      const int myl = half ? len[j + 1] : len[j];
+      const int pos = (half && mx > 1) ? 31 - l32 : l32;
+      if (pos < myl) emit(k, half ? a[j + 1] : a[j], pos);
+    } else {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int ln = len[j + u];
+        if (ln == 0) continue;
+        u64 k = key[j + u];
+        if (ln > 32) k = wave_bitonic<64>(k, lane);
+        else if (ln > 16) k = wave_bitonic<32>(k, lane);
+        else if (ln > 8) k = wave_bitonic<16>(k, lane);
+        else if (ln > 1) k = wave_bitonic<8>(k, lane);
+        if (lane < ln) emit(k, a[j + u], lane);
+      }
     }
   }
 }
