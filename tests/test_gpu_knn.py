@@ -158,6 +158,14 @@ def test_large_skewed_batches_through_the_two_level_query_order(capi, orc):
             d = q[good] - pts[gi[good][:, 0]]
             rec = ((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]).astype(np.float32)
             assert np.array_equal(rec, gd[good][:, 0])
+    # exactly the threshold size; a tree whose box has no extent (every cell number is 0: one bin holds the batch)
+    q = util.uniform_cloud(32_768, 54, 0, 1024)
+    gi, gd = tree.knn(q, 8)
+    oi, od = otree.knn(q[:3000], 8, nthreads=8)
+    assert np.array_equal(gi[:3000], oi) and np.array_equal(gd[:3000].view(np.int32), od.view(np.int32))
+    flat = capi.Tree(np.full((50, 3), 7.0, np.float32))
+    gi, gd = flat.knn(q, 3)
+    assert (gi == np.array([0, 1, 2])).all() and np.array_equal(gd[:, 0], gd[:, 2])
     # radius search shares the ordering
     ro, ri, rd = tree.radius(corner, 12.0)
     oo, oi, od = otree.radius(corner[:2000], 12.0)
