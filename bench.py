@@ -333,7 +333,7 @@ def cpu_baseline(target, q_host, idx, d2):
     from oracle import pcl_oracle as orc
     cores = min(16, len(os.sched_getaffinity(0)))
     tree = orc.Tree(target)
-    reps = 3
+    reps = 6  # ~10 core-seconds of CPU work on 16 cores
     nq = len(q_host)
     orc.Tree.knn(tree, q_host[:20000], K, nthreads=cores)  # thread-pool warm-up
     t0 = time.perf_counter()
