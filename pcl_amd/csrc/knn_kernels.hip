@@ -687,7 +687,16 @@ int launch_knn(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, s
     constexpr int WPB = 4;
     unsigned waves = (unsigned)((nq + 63) / 64);
     unsigned blocks = ((waves + WPB - 1) / WPB + 7) & ~7u;
-    if (nn1_per_lane()) {
+    // Per-lane walk or wave-uniform walk: the wave-uniform one wins when the batch is about as dense as the target
+    // or denser (its 64 queries then share most of their nodes: 4.9e9 against 3.5e9 queries/s with 3 queries per
+    // target point, 0.254 against 0.281 ms at 1M x 1M), the per-lane one on sparse batches (0.11 against 0.16 ms for
+    // 100k queries on a 1M-point target).  PCLMI_NN1=union / lane forces one of them (development switch).
+    static const int forced = [] {
+      const char *e = getenv("PCLMI_NN1");
+      return !e ? 0 : (e[0] == 'u' ? 1 : (e[0] == 'l' ? 2 : 0));
+    }();
+    const bool per_lane = forced ? forced == 2 : nq * 2 < t->n;
+    if (per_lane) {
       const int levels = lane_nearest_levels(t->M);
       hipLaunchKernelGGL((knn1_lane_kernel<WPB>), dim3(blocks), dim3(64 * WPB), (size_t)WPB * levels * 64 * sizeof(float),
                          s, t->view(), d_q, (int)qsf, order, (int)nq, levels, d_idx, d_d2);
