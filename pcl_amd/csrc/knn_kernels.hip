@@ -152,6 +152,50 @@ __device__ __forceinline__ int compact_index_buffer(unsigned int (*buf)[64], con
   return n;
 }
 
+// Shared epilogue of the k-NN kernels: filter the lane's buffer with the exact k-th distance, sort the survivors by
+// (d2, index), store the row.
+template <int K, int C>
+__device__ __forceinline__ void knn_finish(unsigned int (*buf)[64], const float4 *__restrict__ cloud, const LaneQuery &lq,
+                                           int lane, int cnt, float tau, int k_out, int *__restrict__ out_idx,
+                                           float *__restrict__ out_d2) {
+  const float qx = lq.x, qy = lq.y, qz = lq.z;
+  float dk[K];
+  unsigned int ik[K];
+  // ---- final: filter with the exact k-th distance, sort the survivors by (d2, index)
+  cnt = compact_index_buffer<K, C>(buf, cloud, qx, qy, qz, lane, cnt, tau, dk, ik, true);
+  unsigned long long key[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) key[j] = j < cnt ? (((unsigned long long)__float_as_uint(dk[j]) << 32) | ik[j]) : ~0ull;
+  sort_keys<K>(key);
+  if (lq.alive) {
+    int *oi = out_idx + (size_t)lq.qi * k_out;
+    float *od = out_d2 + (size_t)lq.qi * k_out;
+    // full rows on 16-byte boundaries (the usual case): 128-bit stores - a 4-byte store per neighbour makes every
+    // store instruction touch 64 different cache lines
+    const bool wide = K % 4 == 0 && k_out == K &&
+                      ((((unsigned long long)out_idx | (unsigned long long)out_d2) & 15ull) == 0ull);
+    if (wide) {
+#pragma unroll
+      for (int j = 0; j + 3 < K; j += 4) {
+        reinterpret_cast<int4 *>(oi)[j / 4] =
+            make_int4((int)(unsigned int)key[j], (int)(unsigned int)key[j + 1], (int)(unsigned int)key[j + 2],
+                      (int)(unsigned int)key[j + 3]);
+        reinterpret_cast<float4 *>(od)[j / 4] =
+            make_float4(__uint_as_float((unsigned int)(key[j] >> 32)), __uint_as_float((unsigned int)(key[j + 1] >> 32)),
+                        __uint_as_float((unsigned int)(key[j + 2] >> 32)), __uint_as_float((unsigned int)(key[j + 3] >> 32)));
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        if (j < k_out) {
+          oi[j] = (int)(unsigned int)(key[j] & 0xffffffffull);
+          od[j] = __uint_as_float((unsigned int)(key[j] >> 32));
+        }
+      }
+    }
+  }
+}
+
 template <int K, int C, int WPB>
 __global__ __launch_bounds__(64 * WPB) void knn_union_ix_kernel(TreeView t, const float *__restrict__ q,
                                                                  int q_stride_f, const int *__restrict__ order,
@@ -230,39 +274,61 @@ __global__ __launch_bounds__(64 * WPB) void knn_union_ix_kernel(TreeView t, cons
   }
   PCLMI_STAT(6, 1);
 
-  // ---- final: filter with the exact k-th distance, sort the survivors by (d2, index)
-  cnt = compact_index_buffer<K, C>(buf, cloud, qx, qy, qz, lane, cnt, a[K - 1], dk, ik, true);
-  unsigned long long key[K];
+  knn_finish<K, C>(buf, cloud, lq, lane, cnt, a[K - 1], k_out, out_idx, out_d2);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K >= 2, SPARSE batches (far fewer queries than target points): the 64 queries of a wavefront are then far apart,
+// the union of their search balls is most of a subtree (10 000 queries on a 1M-point target: ~400 buckets per wave
+// against ~10 per query), and every lane walking for itself (traverse.hpp lane_traverse) wins although its loads
+// diverge.  Same bookkeeping as the union kernel: K running distances in registers, index-only append buffer in
+// LDS, compaction when a bucket's worth of room is no longer free, shared epilogue.
+template <int K, int C>
+__global__ __launch_bounds__(64) void knn_lane_ix_kernel(TreeView t, const float *__restrict__ q, int q_stride_f,
+                                                         const int *__restrict__ order, int nq, int levels, int k_out,
+                                                         int *__restrict__ out_idx, float *__restrict__ out_d2) {
+  static_assert(C >= K + L + 8, "buffer must hold the K best plus one bucket of appends");
+  extern __shared__ float far_lds[];  // levels x 64 floats
+  __shared__ unsigned int lds[C][64];
+  const int lane = threadIdx.x & 63;
+  LaneQuery lq;
+  if (!load_lane_query<1>(q, q_stride_f, order, nq, lq)) return;
+  const float qx = lq.x, qy = lq.y, qz = lq.z;
+  unsigned int(*buf)[64] = lds;
+  const float4 *cloud = reinterpret_cast<const float4 *>(t.slot);
+  const float bound = lq.searchable ? lane_bound<K>(t, qx, qy, qz) : -1.f;
+  float a[K];
 #pragma unroll
-  for (int j = 0; j < K; ++j) key[j] = j < cnt ? (((unsigned long long)__float_as_uint(dk[j]) << 32) | ik[j]) : ~0ull;
-  sort_keys<K>(key);
-  if (lq.alive) {
-    int *oi = out_idx + (size_t)lq.qi * k_out;
-    float *od = out_d2 + (size_t)lq.qi * k_out;
-    // full rows on 16-byte boundaries (the usual case): 128-bit stores - a 4-byte store per neighbour makes every
-    // store instruction touch 64 different cache lines
-    const bool wide = K % 4 == 0 && k_out == K &&
-                      ((((unsigned long long)out_idx | (unsigned long long)out_d2) & 15ull) == 0ull);
-    if (wide) {
+  for (int j = 0; j < K; ++j) a[j] = bound;
+  int cnt = 0;
+  float dk[K];
+  unsigned int ik[K];
+  const f2v q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
+  lane_traverse(
+      t, qx, qy, qz, lq.searchable, bound, reinterpret_cast<float(*)[64]>(far_lds), lane, 1,
+      [&](int leafno, float) {
+        const float4 *rec = reinterpret_cast<const float4 *>(t.leaf + (size_t)leafno * (4 * L));
 #pragma unroll
-      for (int j = 0; j + 3 < K; j += 4) {
-        reinterpret_cast<int4 *>(oi)[j / 4] =
-            make_int4((int)(unsigned int)key[j], (int)(unsigned int)key[j + 1], (int)(unsigned int)key[j + 2],
-                      (int)(unsigned int)key[j + 3]);
-        reinterpret_cast<float4 *>(od)[j / 4] =
-            make_float4(__uint_as_float((unsigned int)(key[j] >> 32)), __uint_as_float((unsigned int)(key[j + 1] >> 32)),
-                        __uint_as_float((unsigned int)(key[j + 2] >> 32)), __uint_as_float((unsigned int)(key[j + 3] >> 32)));
-      }
-    } else {
+        for (int g = 0; g < G; ++g) {
+          const float4 X = rec[g * 4 + 0], Y = rec[g * 4 + 1], Z = rec[g * 4 + 2];
+          const f2v d01 = sq3_pk(q2x - f2v{X.x, X.y}, q2y - f2v{Y.x, Y.y}, q2z - f2v{Z.x, Z.y});
+          const f2v d23 = sq3_pk(q2x - f2v{X.z, X.w}, q2y - f2v{Y.z, Y.w}, q2z - f2v{Z.z, Z.w});
+          const float dd[4] = {d01.x, d01.y, d23.x, d23.y};
 #pragma unroll
-      for (int j = 0; j < K; ++j) {
-        if (j < k_out) {
-          oi[j] = (int)(unsigned int)(key[j] & 0xffffffffull);
-          od[j] = __uint_as_float((unsigned int)(key[j] >> 32));
+          for (int j = 0; j < 4; ++j) {
+            if (dd[j] <= a[K - 1]) {
+              buf[cnt][lane] = (unsigned int)leafno * L + g * 4 + j;  // bucket slot
+              ++cnt;
+              list_insert<K>(a, dd[j]);
+            }
+          }
         }
-      }
-    }
-  }
+        return a[K - 1];
+      },
+      [&] {  // once per round, wave converged: make room for the next bucket
+        if (__any(cnt > C - L)) cnt = compact_index_buffer<K, C>(buf, cloud, qx, qy, qz, lane, cnt, a[K - 1], dk, ik, false);
+      });
+  knn_finish<K, C>(buf, cloud, lq, lane, cnt, a[K - 1], k_out, out_idx, out_d2);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -678,6 +744,28 @@ static void launch_union_ix(const pclmi_tree *t, const float *d_q, size_t nq, si
                      (int)qsf, order, (int)nq, k_eff, d_idx, d_d2);
 }
 
+template <int K, int C>
+static void launch_lane_ix(const pclmi_tree *t, const float *d_q, size_t nq, size_t qsf, const int32_t *order,
+                           int k_eff, int32_t *d_idx, float *d_d2, hipStream_t s) {
+  const int levels = lane_nearest_levels(t->M);
+  const unsigned blocks = (((unsigned)((nq + 63) / 64)) + 7) & ~7u;
+  hipLaunchKernelGGL((knn_lane_ix_kernel<K, C>), dim3(blocks), dim3(64), (size_t)levels * 64 * sizeof(float), s, t->view(),
+                     d_q, (int)qsf, order, (int)nq, levels, k_eff, d_idx, d_d2);
+}
+
+// sparse batch: the per-lane kernels (measured crossover); PCLMI_KNN=union / lane forces one
+static bool knn_sparse(const pclmi_tree *t, size_t nq) {
+  static const int forced = [] {
+    const char *e = getenv("PCLMI_KNN");
+    return !e ? 0 : (e[0] == 'u' ? 1 : (e[0] == 'l' ? 2 : 0));
+  }();
+  static const size_t ratio = [] {
+    const char *e = getenv("PCLMI_KNN_SPARSE_RATIO");
+    return e ? (size_t)atoi(e) : (size_t)4;
+  }();
+  return forced ? forced == 2 : nq * ratio < t->n;
+}
+
 int launch_knn(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, size_t qsf,
                const int32_t *order, int k_eff, int32_t *d_idx, float *d_d2, hipStream_t s) {
   if (nq == 0 || k_eff <= 0) return PCLMI_OK;
@@ -704,6 +792,11 @@ int launch_knn(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, s
       hipLaunchKernelGGL((knn1_union_kernel<WPB>), dim3(blocks), dim3(64 * WPB), 0, s, t->view(), d_q, (int)qsf,
                          order, (int)nq, d_idx, d_d2);
     }
+  } else if (k_eff <= 32 && knn_sparse(t, nq)) {
+    if (k_eff <= 4) launch_lane_ix<4, 32>(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
+    else if (k_eff <= 8) launch_lane_ix<8, 32>(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
+    else if (k_eff <= 16) launch_lane_ix<16, 40>(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
+    else launch_lane_ix<32, 64>(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
   } else if (k_eff <= 2) {
     launch_union_ix<2, 16, 1>(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
   } else if (k_eff <= 4) {

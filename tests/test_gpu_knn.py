@@ -75,6 +75,36 @@ def test_grid_ties(capi, orc, k):
     _check(capi, orc, pts, q, k)
 
 
+@pytest.mark.parametrize("k", [2, 3, 4, 5, 8, 10, 16, 20, 32])
+def test_sparse_batches_take_the_per_lane_kernel(capi, orc, k):
+    """Fewer than a quarter as many queries as target points: knn_lane_ix_kernel (each lane walks for itself).  The
+    same bars as the union kernel: ties on a grid, duplicates beyond a bucket, NaN queries, a ragged last wave - and
+    both kernels must agree on one batch (PCLMI_KNN is read once per process, so the batch sizes pick the kernels)."""
+    pts = util.grid_cloud()  # 1331 points, many exactly-equal distances
+    q = np.concatenate([pts[::11], np.array([[0.01, 0.01, 0.01], [0, 0, 0], [0.05, 0.05, 0.05]], np.float32),
+                        pts[:100] + np.float32(0.05)])
+    assert len(q) * 4 < len(pts)
+    _check(capi, orc, pts, q, k)
+    rng = np.random.default_rng(61)
+    base = rng.random((60, 3), dtype=np.float32)
+    dup = np.repeat(base, 40, axis=0)  # 2400 points, each value 40 times
+    qq = np.concatenate([base, rng.random((139, 3), dtype=np.float32)])
+    qq[17] = np.nan
+    t = capi.Tree(dup)
+    gi, gd = t.knn(qq, k)
+    good = np.isfinite(qq).all(axis=1)
+    oi, od = orc.knn_brute(dup, qq[good], k)
+    assert np.array_equal(gi[good], oi) and np.array_equal(gd[good].view(np.int32), od.view(np.int32))
+    assert (gi[~good] == -1).all() and np.isnan(gd[~good]).all()
+    big = util.uniform_cloud(120_000, 62, 0, 100)
+    tb = capi.Tree(big)
+    sparse = util.uniform_cloud(20_001, 63, 0, 100)
+    dense = np.concatenate([sparse, util.uniform_cloud(20_000, 64, 0, 100)])  # 40 001 * 4 > 120 000: union kernel
+    si, sd = tb.knn(sparse, k)
+    di, dd = tb.knn(dense, k)
+    assert np.array_equal(si, di[:20_001]) and np.array_equal(sd.view(np.int32), dd[:20_001].view(np.int32))
+
+
 def test_duplicates_and_tiny_clouds(capi, orc):
     rng = np.random.default_rng(5)
     base = rng.random((40, 3), dtype=np.float32)
