@@ -107,6 +107,74 @@ __global__ __launch_bounds__(64 * R_WPB) void radius_union_kernel(TreeView t, co
   }
 }
 
+// Sparse batches (fewer than a quarter as many queries as target points): every lane walks for itself
+// (traverse.hpp lane_traverse) under the fixed bound - the union of 64 far-apart search balls is most of a subtree
+// (10 000 queries on a 1M-point target: 0.67 ms for the union walk).  Same three modes and outputs.
+template <int MODE>
+__global__ __launch_bounds__(64) void radius_lane_kernel(TreeView t, const float *__restrict__ q, int q_stride_f,
+                                                         const int *__restrict__ order, int nq, int levels, float r2,
+                                                         float tau_r, int by_index, unsigned int *__restrict__ counts,
+                                                         const u64 *__restrict__ offsets, u64 *__restrict__ keys,
+                                                         unsigned int *__restrict__ n_over) {
+  constexpr bool FILL = MODE == 1;
+  extern __shared__ float far_lds[];  // levels x 64 floats
+  const int lane = threadIdx.x & 63;
+  LaneQuery lq;
+  if (!load_lane_query<1>(q, q_stride_f, order, nq, lq)) return;
+  const float qx = lq.x, qy = lq.y, qz = lq.z;
+  unsigned int cnt = 0;
+  u64 *out = nullptr;
+  if (FILL && lq.alive) out = keys + offsets[lq.qi];
+  if (MODE == 2 && lq.alive) out = keys + (size_t)lq.qi * PROV_CAP;
+  const f2v q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
+  lane_traverse(
+      t, qx, qy, qz, lq.searchable, tau_r, reinterpret_cast<float(*)[64]>(far_lds), lane, 1,
+      [&](int leafno, float tau) {
+        const float4 *rec = reinterpret_cast<const float4 *>(t.leaf + (size_t)leafno * (4 * L));
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const float4 X = rec[g * 4 + 0], Y = rec[g * 4 + 1], Z = rec[g * 4 + 2], I = rec[g * 4 + 3];
+          const f2v d01 = sq3_pk(q2x - f2v{X.x, X.y}, q2y - f2v{Y.x, Y.y}, q2z - f2v{Z.x, Z.y});
+          const f2v d23 = sq3_pk(q2x - f2v{X.z, X.w}, q2y - f2v{Y.z, Y.w}, q2z - f2v{Z.z, Z.w});
+          const float dd[4] = {d01.x, d01.y, d23.x, d23.y};
+          const float ii[4] = {I.x, I.y, I.z, I.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (dd[j] < r2) {  // padded slots are at +inf
+              if (FILL || (MODE == 2 && cnt < (unsigned int)PROV_CAP)) {
+                const unsigned int ib = __float_as_uint(ii[j]), db = __float_as_uint(dd[j]);
+                out[cnt] = by_index ? (((u64)ib << 32) | db) : (((u64)db << 32) | ib);
+              }
+              ++cnt;
+            }
+          }
+        }
+        return tau;
+      },
+      [] {});
+  if (!FILL && lq.alive) counts[lq.qi] = cnt;
+  if (MODE == 2) {
+    const int over = __popcll(__ballot(cnt > (unsigned int)PROV_CAP));
+    if (over && lane == 0) atomicAdd(n_over, (unsigned int)over);
+  }
+}
+
+template <int MODE>
+void launch_radius_traversal(const pclmi_tree *t, bool per_lane, const float *d_q, int qsf, const int *order, int nq,
+                             float r2, float tau_r, int by_index, unsigned int *counts, const u64 *offsets, u64 *keys,
+                             unsigned int *n_over, hipStream_t s) {
+  const unsigned waves = (unsigned)((nq + 63) / 64);
+  if (per_lane) {
+    const int levels = lane_nearest_levels(t->M);
+    hipLaunchKernelGGL((radius_lane_kernel<MODE>), dim3((waves + 7) & ~7u), dim3(64), (size_t)levels * 64 * sizeof(float),
+                       s, t->view(), d_q, qsf, order, nq, levels, r2, tau_r, by_index, counts, offsets, keys, n_over);
+  } else {
+    const unsigned blocks = ((waves + R_WPB - 1) / R_WPB + 7) & ~7u;
+    hipLaunchKernelGGL((radius_union_kernel<MODE>), dim3(blocks), dim3(64 * R_WPB), 0, s, t->view(), d_q, qsf, order, nq,
+                       r2, tau_r, by_index, counts, offsets, keys, n_over);
+  }
+}
+
 // ---- per-segment sort ------------------------------------------------------------------------
 // One wave per segment of up to SEG_MAX keys: load into LDS (padded with ~0), bitonic network,
 // store back.  Short segments (the common case, ~32 entries) take log^2 steps over 64 slots.
@@ -474,8 +542,12 @@ int radius_search_dev(const pclmi_tree *t, Workspace *w, const float *d_q, size_
   PCLMI_HIP(hipMemsetAsync(d_counts, 0, counts_bytes, s));
   const float tau_r = nextafterf(r2, 0.f);  // largest float < r2 (r2 > 0)
   const int by_index = (!sorted && !max_nn) ? 1 : 0;
-  const unsigned waves = (unsigned)((nq + 63) / 64);
-  const unsigned blocks = ((waves + R_WPB - 1) / R_WPB + 7) & ~7u;
+  // sparse batch: the per-lane walk (PCLMI_KNN=union / lane forces one, as for k-NN)
+  static const int forced = [] {
+    const char *e = getenv("PCLMI_KNN");
+    return !e ? 0 : (e[0] == 'u' ? 1 : (e[0] == 'l' ? 2 : 0));
+  }();
+  const bool per_lane = forced ? forced == 2 : nq * 4 < t->n;
   // One traversal when it can be enough: count and keep the first PROV_CAP keys of every query in a fixed-pitch
   // row; if no query has more, the rows are sorted into the output and the fill traversal never runs.
   unsigned int *d_nover = d_nlong + 2;
@@ -491,12 +563,11 @@ int radius_search_dev(const pclmi_tree *t, Workspace *w, const float *d_q, size_
   {
     TimingScope ts(PCLMI_TIMER_RADIUS, s);
     if (try_prov)
-      hipLaunchKernelGGL((radius_union_kernel<2>), dim3(blocks), dim3(64 * R_WPB), 0, s, t->view(), d_q, (int)qsf,
-                         order, (int)nq, r2, tau_r, by_index, d_counts, (const u64 *)nullptr, prov, d_nover);
+      launch_radius_traversal<2>(t, per_lane, d_q, (int)qsf, order, (int)nq, r2, tau_r, by_index, d_counts,
+                                 (const u64 *)nullptr, prov, d_nover, s);
     else
-      hipLaunchKernelGGL((radius_union_kernel<0>), dim3(blocks), dim3(64 * R_WPB), 0, s, t->view(), d_q, (int)qsf,
-                         order, (int)nq, r2, tau_r, by_index, d_counts, (const u64 *)nullptr, (u64 *)nullptr,
-                         (unsigned int *)nullptr);
+      launch_radius_traversal<0>(t, per_lane, d_q, (int)qsf, order, (int)nq, r2, tau_r, by_index, d_counts,
+                                 (const u64 *)nullptr, (u64 *)nullptr, (unsigned int *)nullptr, s);
   }
   rc = scan_counts(w, d_counts, nq, d_off_full, s);
   if (rc) return rc;
@@ -540,9 +611,8 @@ int radius_search_dev(const pclmi_tree *t, Workspace *w, const float *d_q, size_
   u64 *keys = (u64 *)w->buf[1], *alt = keys + total;
   {
     TimingScope ts(PCLMI_TIMER_RADIUS, s);
-    hipLaunchKernelGGL((radius_union_kernel<1>), dim3(blocks), dim3(64 * R_WPB), 0, s, t->view(), d_q, (int)qsf,
-                       order, (int)nq, r2, tau_r, by_index, (unsigned int *)nullptr, (const u64 *)d_off_full, keys,
-                       (unsigned int *)nullptr);
+    launch_radius_traversal<1>(t, per_lane, d_q, (int)qsf, order, (int)nq, r2, tau_r, by_index, (unsigned int *)nullptr,
+                               (const u64 *)d_off_full, keys, (unsigned int *)nullptr, s);
   }
   int32_t *oi = nullptr;
   float *od = nullptr;

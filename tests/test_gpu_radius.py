@@ -111,3 +111,26 @@ def test_surface_like_cloud(capi, orc):
     q = np.concatenate([pts[::40] + np.float32(0.2), rng.random((300, 3), dtype=np.float32) * 300 - 100]).astype(np.float32)
     t = capi.Tree(pts)
     _same(t.radius(q, 1.5), orc.Tree(pts).radius(q, 1.5, nthreads=8))
+
+
+def test_sparse_batches_take_the_per_lane_kernel(capi, orc):
+    """Fewer than a quarter as many queries as target points: radius_lane_kernel (count, fill and provisional-row
+    modes).  Grid ties at the strict radius, max_nn, unsorted output, more than 64 hits per query (two-traversal
+    path), NaN queries - and the same batch embedded in a dense one (union kernel) gives the same rows."""
+    pts = util.grid_cloud()  # 1331 points
+    q = np.concatenate([pts[::13], pts[:50] + np.float32(0.05)])
+    q[3] = np.nan
+    assert len(q) * 4 < len(pts)
+    t = capi.Tree(pts)
+    for r in (0.1, 0.15, 0.31, 2.0):  # 0.31: > 64 hits for inner grid points; 2.0: everything in range
+        for max_nn, srt in ((0, True), (0, False), (7, True), (7, False)):
+            _same(t.radius(q, r, max_nn, srt), orc.radius_brute(pts, q, r, max_nn, srt))
+    big = util.uniform_cloud(150_000, 71, 0, 100)
+    tb = capi.Tree(big)
+    sparse = util.uniform_cloud(30_001, 72, 0, 100)
+    dense = np.concatenate([sparse, util.uniform_cloud(10_000, 73, 0, 100)])  # 40 001 * 4 > 150 000: union kernel
+    so, si, sd = tb.radius(sparse, 2.5)
+    do, di, dd = tb.radius(dense, 2.5)
+    n = int(so[-1])
+    assert np.array_equal(so, do[:30_002]) and np.array_equal(si, di[:n]) and np.array_equal(sd.view(np.int32), dd[:n].view(np.int32))
+    _same(tb.radius(sparse[:3000], 2.5), orc.Tree(big).radius(sparse[:3000], 2.5, nthreads=8))
