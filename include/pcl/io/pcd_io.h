@@ -45,9 +45,31 @@ struct PCDHeader {
   size_t data_offset = 0;
 };
 
+// Rejects, like the reference reader (io/src/pcd_io.cpp readHeader), any header whose SIZE / TYPE / COUNT / WIDTH /
+// HEIGHT / POINTS entries are missing where required, unparsable, negative or inconsistent: the binary path
+// computes record offsets from them.
 inline int readHeader(std::istream &f, PCDHeader &h) {
   std::string line;
-  bool have_points = false;
+  bool have_points = false, bad = false;
+  // every entry of a per-field line must parse and no extra token may follow
+  auto per_field = [&](std::istringstream &ss, auto setter) {
+    for (auto &fd : h.fields) {
+      if (!setter(ss, fd)) {
+        bad = true;
+        return;
+      }
+    }
+    std::string extra;
+    if (ss >> extra) bad = true;
+  };
+  auto read_count = [&](std::istringstream &ss, unsigned long long &v) {
+    long long t = -1;
+    if (!(ss >> t) || t < 0) {
+      bad = true;
+      return;
+    }
+    v = static_cast<unsigned long long>(t);
+  };
   while (std::getline(f, line)) {
     if (!line.empty() && line.back() == '\r') line.pop_back();
     if (line.empty() || line[0] == '#') continue;
@@ -64,17 +86,31 @@ inline int readHeader(std::istream &f, PCDHeader &h) {
         h.fields.push_back(fd);
       }
     } else if (key == "SIZE") {
-      for (auto &fd : h.fields) ss >> fd.size;
+      per_field(ss, [](std::istringstream &s, PCDField &fd) {
+        return static_cast<bool>(s >> fd.size) && (fd.size == 1 || fd.size == 2 || fd.size == 4 || fd.size == 8);
+      });
     } else if (key == "TYPE") {
-      for (auto &fd : h.fields) ss >> fd.type;
+      per_field(ss, [](std::istringstream &s, PCDField &fd) {
+        return static_cast<bool>(s >> fd.type) && (fd.type == 'F' || fd.type == 'I' || fd.type == 'U');
+      });
     } else if (key == "COUNT") {
-      for (auto &fd : h.fields) ss >> fd.count;
+      per_field(ss, [](std::istringstream &s, PCDField &fd) {
+        return static_cast<bool>(s >> fd.count) && fd.count >= 1 && fd.count <= (1 << 20);
+      });
     } else if (key == "WIDTH") {
-      ss >> h.width;
+      unsigned long long v = 0;
+      read_count(ss, v);
+      if (v > 0xffffffffull) bad = true;
+      h.width = static_cast<std::uint32_t>(v);
     } else if (key == "HEIGHT") {
-      ss >> h.height;
+      unsigned long long v = 0;
+      read_count(ss, v);
+      if (v > 0xffffffffull) bad = true;
+      h.height = static_cast<std::uint32_t>(v);
     } else if (key == "POINTS") {
-      ss >> h.points;
+      unsigned long long v = 0;
+      read_count(ss, v);
+      h.points = static_cast<size_t>(v);
       have_points = true;
     } else if (key == "DATA") {
       ss >> h.data;
@@ -82,7 +118,7 @@ inline int readHeader(std::istream &f, PCDHeader &h) {
       break;
     }
   }
-  if (h.fields.empty() || h.data.empty()) return -1;
+  if (bad || h.fields.empty() || h.data.empty()) return -1;
   if (!have_points) h.points = static_cast<size_t>(h.width) * h.height;
   if (h.width == 0) {  // old files without WIDTH / HEIGHT
     h.width = static_cast<std::uint32_t>(h.points);
@@ -90,11 +126,11 @@ inline int readHeader(std::istream &f, PCDHeader &h) {
   }
   size_t off = 0;
   for (auto &fd : h.fields) {
-    if (fd.count < 1) fd.count = 1;
     fd.offset = off;
-    off += static_cast<size_t>(fd.size) * fd.count;
+    off += static_cast<size_t>(fd.size) * static_cast<size_t>(fd.count);  // <= 8 * 2^20 per field: no overflow
   }
   h.record = off;
+  if (h.record == 0) return -1;
   return 0;
 }
 }  // namespace detail
@@ -123,6 +159,21 @@ int loadPCDFile(const std::string &file_name, pcl::PointCloud<PointT> &cloud) {
   if (fx < 0 || fy < 0 || fz < 0) {
     PCL_ERROR("[pcl::PCDReader::read] %s: fields x y z (F 4) not found.\n", file_name.c_str());
     return -1;
+  }
+  // the payload bounds the point count: a binary record is h.record bytes, an ASCII row at least two bytes per
+  // field ("0 "), so a header announcing more points than the file can hold is refused before anything is allocated
+  {
+    f.clear();
+    f.seekg(0, std::ios::end);
+    const std::streamoff end = f.tellg();
+    const size_t remaining = end > static_cast<std::streamoff>(h.data_offset)
+                                 ? static_cast<size_t>(end) - h.data_offset : 0;
+    const size_t per_point = h.data == "binary" ? h.record : 2 * h.fields.size();
+    if (per_point == 0 || h.points > remaining / per_point + (h.data == "binary" ? 0 : 1)) {
+      PCL_ERROR("[pcl::PCDReader::read] %s: header announces %zu points, the file holds fewer.\n", file_name.c_str(),
+                h.points);
+      return -1;
+    }
   }
   cloud.points.assign(h.points, PointT());
   cloud.width = h.width;

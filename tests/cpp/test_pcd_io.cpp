@@ -61,6 +61,29 @@ int main(int argc, char **argv) {
   }
   EXPECT(pcl::io::loadPCDFile(tmp + "/e.pcd", back) == -1);
   EXPECT(pcl::io::savePCDFile(tmp + "/f.pcd", pcl::PointCloud<pcl::PointXYZ>()) == -1);
+  // malformed headers are refused before anything is read or allocated: negative / odd / missing SIZE entries
+  // (record offsets would wrap), COUNT 0, a point count the payload cannot hold, negative counts
+  {
+    const char *bad[] = {
+        "VERSION .7\nFIELDS x y z w\nSIZE 4 4 4 -4\nTYPE F F F F\nCOUNT 1 1 1 1\nWIDTH 1\nHEIGHT 1\nPOINTS 1\nDATA binary\n",
+        "VERSION .7\nFIELDS x y z\nSIZE 4 4 3\nTYPE F F F\nCOUNT 1 1 1\nWIDTH 1\nHEIGHT 1\nPOINTS 1\nDATA binary\n",
+        "VERSION .7\nFIELDS x y z\nSIZE 4 4\nTYPE F F F\nCOUNT 1 1 1\nWIDTH 1\nHEIGHT 1\nPOINTS 1\nDATA binary\n",
+        "VERSION .7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F Q\nCOUNT 1 1 1\nWIDTH 1\nHEIGHT 1\nPOINTS 1\nDATA binary\n",
+        "VERSION .7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 0\nWIDTH 1\nHEIGHT 1\nPOINTS 1\nDATA binary\n",
+        "VERSION .7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\nWIDTH 1\nHEIGHT 1\nPOINTS 18446744073709551615\nDATA binary\n",
+        "VERSION .7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\nWIDTH 1\nHEIGHT 1\nPOINTS 4611686018427387904\nDATA binary\n",
+        "VERSION .7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\nWIDTH 1\nHEIGHT 1\nPOINTS 1000000000000\nDATA ascii\n1 2 3\n",
+        "VERSION .7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\nWIDTH -1\nHEIGHT 1\nPOINTS 1\nDATA ascii\n1 2 3\n",
+        "VERSION .7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\nWIDTH 1\nHEIGHT 1\nPOINTS -1\nDATA ascii\n1 2 3\n",
+    };
+    for (size_t b = 0; b < sizeof(bad) / sizeof(bad[0]); ++b) {
+      {
+        std::ofstream f(tmp + "/g.pcd", std::ios::binary);
+        f << bad[b] << std::string(12, '\0');  // one record of payload
+      }
+      EXPECT(pcl::io::loadPCDFile(tmp + "/g.pcd", back) == -1);
+    }
+  }
   std::printf(g_fail ? "test_pcd_io: %d FAILED\n" : "test_pcd_io: all checks passed\n", g_fail);
   return g_fail ? 1 : 0;
 }
