@@ -15,8 +15,8 @@
  *    DEVICE pointers (inputs already resident in HBM) and enqueue on `stream`
  *    (a hipStream_t passed as void*, NULL = the library's stream for that tree).  The search
  *    entry points (pclmi_knn_dev, pclmi_radius_dev, pclmi_normals_dev) return once their work
- *    on `stream` has completed (their scratch goes back to a pool); the ICP step / solve entry
- *    points only enqueue.
+ *    on `stream` has completed (their scratch goes back to a pool); pclmi_knn_dev_async and the
+ *    ICP step / solve entry points only enqueue.
  *  - Squared L2 distances are fp32, computed as ((dx*dx + dy*dy) + dz*dz) with one rounding
  *    per operation (flann::L2_Simple<float>, kdtree/include/pcl/kdtree/kdtree_flann.h:56).
  *  - Neighbour lists are ascending in the total order (d2, index): exact search, eps = 0,
@@ -104,6 +104,13 @@ int pclmi_knn(const pclmi_tree *t, const float *queries, size_t nq, size_t q_str
  * min(k, pclmi_tree_size) entries. */
 int pclmi_knn_dev(const pclmi_tree *t, const float *d_queries, size_t nq, size_t q_stride_bytes,
                   int k, int32_t *d_idx, float *d_d2, void *stream);
+/* Same, but only ENQUEUES on `stream` and returns: the batched form of the reference's per-point loop
+ * (search.h:244-262) for callers that pipeline uploads, searches and downloads of consecutive batches (the
+ * 100M-query sweep of BASELINE configs[4]).  The call's scratch is taken from the tree's workspace pool and handed
+ * back in stream order: a later call on another stream is ordered behind this one's kernels with an event, never by
+ * blocking the host.  Outputs are valid once the work queued on `stream` has completed. */
+int pclmi_knn_dev_async(const pclmi_tree *t, const float *d_queries, size_t nq, size_t q_stride_bytes,
+                        int k, int32_t *d_idx, float *d_d2, void *stream);
 
 /* Radius search ----------------------------------------------------------------------
  * Replaces pcl::KdTreeFLANN::radiusSearch (impl/kdtree_flann.hpp:115-157) and the batched

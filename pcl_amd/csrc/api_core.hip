@@ -161,7 +161,17 @@ void dev_cache_put(void *p) {
   if (p) (void)hipFree(p);  // not ours to cache (or too large)
 }
 
+static int fixed_too_small(const char *what, size_t need, size_t have) {
+  set_error("the allocation-free workspace is too small for this call: %s needs %zu, capacity %zu", what, need, have);
+  return PCLMI_ERR_UNSUPPORTED;
+}
+
 int Workspace::ensure_queries(size_t nq, size_t nbins) {
+  if (fixed) {
+    if (nq > cap_q) return fixed_too_small("query slots", nq, cap_q);
+    if (nbins > cap_bins) return fixed_too_small("histogram bins", nbins, cap_bins);
+    return PCLMI_OK;
+  }
   if (nq > cap_q) {
     size_t cap = nq + nq / 8 + 1024;
     if (keys_in) (void)hipFree(keys_in);
@@ -194,6 +204,7 @@ int Workspace::ensure_queries(size_t nq, size_t nbins) {
 
 int Workspace::ensure_scratch(size_t bytes) {
   if (bytes <= cap_scratch) return PCLMI_OK;
+  if (fixed) return fixed_too_small("scratch bytes", bytes, cap_scratch);
   if (scratch) (void)hipFree(scratch);
   scratch = nullptr;
   cap_scratch = 0;
@@ -205,6 +216,7 @@ int Workspace::ensure_scratch(size_t bytes) {
 
 int Workspace::ensure_buf(int which, size_t bytes) {
   if (bytes <= cap_buf[which]) return PCLMI_OK;
+  if (fixed) return fixed_too_small("buffer bytes", bytes, cap_buf[which]);
   if (buf[which]) (void)hipFree(buf[which]);
   buf[which] = nullptr;
   cap_buf[which] = 0;
@@ -215,6 +227,12 @@ int Workspace::ensure_buf(int which, size_t bytes) {
 }
 
 void Workspace::release() {
+  if (ev) (void)hipEventDestroy(ev);
+  ev = nullptr;
+  if (fixed) {  // nothing here is ours
+    *this = Workspace();
+    return;
+  }
   for (int i = 0; i < 4; ++i)
     if (buf[i]) (void)hipFree(buf[i]);
   if (keys_in) (void)hipFree(keys_in);
@@ -226,19 +244,64 @@ void Workspace::release() {
   *this = Workspace();
 }
 
-Workspace *acquire_ws(const pclmi_tree *t) {
-  std::lock_guard<std::mutex> g(t->mu);
-  if (!t->pool.empty()) {
-    Workspace *w = t->pool.back();
-    t->pool.pop_back();
-    return w;
+Workspace *acquire_ws(const pclmi_tree *t, hipStream_t s) {
+  Workspace *w = nullptr;
+  {
+    std::lock_guard<std::mutex> g(t->mu);
+    // prefer a workspace that is idle or whose queued work is on the same stream (stream order is enough then)
+    for (size_t i = t->pool.size(); i-- > 0;)
+      if (!t->pool[i]->in_flight || t->pool[i]->last == s) {
+        w = t->pool[i];
+        t->pool.erase(t->pool.begin() + (long)i);
+        break;
+      }
+    if (!w && !t->pool.empty()) {
+      w = t->pool.back();
+      t->pool.pop_back();
+    }
   }
-  return new Workspace();
+  if (!w) return new Workspace();
+  if (w->in_flight && w->last != s && w->ev) (void)hipStreamWaitEvent(s, w->ev, 0);
+  return w;
 }
 
 void release_ws(const pclmi_tree *t, Workspace *w) {
+  w->in_flight = false;
   std::lock_guard<std::mutex> g(t->mu);
   t->pool.push_back(w);
+}
+
+void release_ws_async(const pclmi_tree *t, Workspace *w, hipStream_t s) {
+  if (!w->ev && hipEventCreateWithFlags(&w->ev, hipEventDisableTiming) != hipSuccess) w->ev = nullptr;
+  if (w->ev && hipEventRecord(w->ev, s) == hipSuccess) {
+    w->in_flight = true;
+    w->last = s;
+  } else {
+    (void)hipStreamSynchronize(s);  // no event: fall back to waiting here
+    w->in_flight = false;
+  }
+  std::lock_guard<std::mutex> g(t->mu);
+  t->pool.push_back(w);
+}
+
+// argument checks + ordering pass + traversal, enqueued on s with workspace w; k_eff == 0 / nq == 0: nothing to do
+int knn_enqueue(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, size_t q_stride_bytes, int k_eff,
+                       int32_t *d_idx, float *d_d2, hipStream_t s) {
+  const int32_t *order = nullptr;
+  RC(launch_morton_order(t, w, d_q, nq, q_stride_bytes / 4, nullptr, nullptr, s, &order));
+  return launch_knn(t, w, d_q, nq, q_stride_bytes / 4, order, k_eff, d_idx, d_d2, s);
+}
+
+int knn_check(const pclmi_tree *t, const float *d_q, size_t nq, size_t q_stride_bytes, int k, int32_t *d_idx,
+                     float *d_d2, int *k_eff) {
+  PCLMI_CHECK(t != nullptr, PCLMI_ERR_INVALID, "tree is NULL");
+  PCLMI_CHECK(k > 0, PCLMI_ERR_INVALID, "k must be positive (got %d)", k);
+  PCLMI_CHECK(q_stride_bytes >= 12 && q_stride_bytes % 4 == 0, PCLMI_ERR_INVALID, "bad query stride %zu",
+              q_stride_bytes);
+  *k_eff = (size_t)k > t->n ? (int)t->n : k;  // impl/kdtree_flann.hpp:85-86
+  if (nq == 0 || *k_eff == 0) return PCLMI_OK;
+  PCLMI_CHECK(d_q && d_idx && d_d2, PCLMI_ERR_INVALID, "NULL query/output pointer");
+  return PCLMI_OK;
 }
 
 }  // namespace pclmi
@@ -400,24 +463,29 @@ size_t pclmi_tree_size(const pclmi_tree *t) { return t ? t->n : 0; }
 
 int pclmi_knn_dev(const pclmi_tree *t, const float *d_q, size_t nq, size_t q_stride_bytes, int k, int32_t *d_idx,
                   float *d_d2, void *stream) {
-  PCLMI_CHECK(t != nullptr, PCLMI_ERR_INVALID, "tree is NULL");
-  PCLMI_CHECK(k > 0, PCLMI_ERR_INVALID, "k must be positive (got %d)", k);
-  PCLMI_CHECK(q_stride_bytes >= 12 && q_stride_bytes % 4 == 0, PCLMI_ERR_INVALID, "bad query stride %zu",
-              q_stride_bytes);
-  const int k_eff = (size_t)k > t->n ? (int)t->n : k;  // impl/kdtree_flann.hpp:85-86
+  int k_eff = 0;
+  RC(knn_check(t, d_q, nq, q_stride_bytes, k, d_idx, d_d2, &k_eff));
   if (nq == 0 || k_eff == 0) return PCLMI_OK;
-  PCLMI_CHECK(d_q && d_idx && d_d2, PCLMI_ERR_INVALID, "NULL query/output pointer");
   PCLMI_HIP(hipSetDevice(t->device));
   hipStream_t s = stream ? (hipStream_t)stream : t->stream;
-  WsGuard g(t);
-  const int32_t *order = nullptr;
-  int rc = launch_morton_order(t, g.w, d_q, nq, q_stride_bytes / 4, nullptr, nullptr, s, &order);
-  if (rc) return rc;
-  rc = launch_knn(t, g.w, d_q, nq, q_stride_bytes / 4, order, k_eff, d_idx, d_d2, s);
-  if (rc) return rc;
+  WsGuard g(t, s);
+  RC(knn_enqueue(t, g.w, d_q, nq, q_stride_bytes, k_eff, d_idx, d_d2, s));
   // the workspace goes back to the pool when this returns: wait for the kernels using it
   PCLMI_HIP(hipStreamSynchronize(s));
   return PCLMI_OK;
+}
+
+int pclmi_knn_dev_async(const pclmi_tree *t, const float *d_q, size_t nq, size_t q_stride_bytes, int k,
+                        int32_t *d_idx, float *d_d2, void *stream) {
+  int k_eff = 0;
+  RC(knn_check(t, d_q, nq, q_stride_bytes, k, d_idx, d_d2, &k_eff));
+  if (nq == 0 || k_eff == 0) return PCLMI_OK;
+  PCLMI_HIP(hipSetDevice(t->device));
+  hipStream_t s = stream ? (hipStream_t)stream : t->stream;
+  Workspace *w = acquire_ws(t, s);
+  const int rc = knn_enqueue(t, w, d_q, nq, q_stride_bytes, k_eff, d_idx, d_d2, s);
+  release_ws_async(t, w, s);  // the next user of w is ordered behind this call's kernels by an event, not the host
+  return rc;
 }
 
 int pclmi_knn(const pclmi_tree *t, const float *q, size_t nq, size_t q_stride_bytes, int k, int32_t *idx,

@@ -242,7 +242,7 @@ int pclmi_icp_begin(const pclmi_tree *target, const float *src, size_t n_src, si
       (rc = c->sums.alloc(PCLMI_ICP_NSUMS)))
     return fail(rc);
   {
-    WsGuard g(target);
+    WsGuard g(target, c->stream);
     const int32_t *d_order = nullptr;
     // stable: the slot order fixes the summation order of the fp64 moments, so it must not vary between runs
     if ((rc = launch_morton_order(target, g.w, (const float *)raw.p, n_src, 4, lo, hi, c->stream, &d_order, true)))

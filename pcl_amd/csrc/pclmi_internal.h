@@ -126,18 +126,29 @@ struct Workspace {
   // further independent scratch buffers (radius search: counts/offsets, key arrays, sort temp)
   void *buf[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t cap_buf[4] = {0, 0, 0, 0};
+  // fixed: the buffers are carved out of memory the workspace does not own (the static scratch of
+  // pclmi_knn_dev_noalloc): ensure_* never allocate, a request beyond the capacities fails with PCLMI_ERR_UNSUPPORTED
+  bool fixed = false;
+  // stream-ordered reuse (pclmi_knn_dev_async): `ev` is recorded on `last` when the workspace goes back to the pool
+  // with work still queued; the next user on another stream waits for it on its stream, not on the host
+  hipEvent_t ev = nullptr;
+  hipStream_t last = nullptr;
+  bool in_flight = false;
   int ensure_queries(size_t nq, size_t nbins);
   int ensure_scratch(size_t bytes);
   int ensure_buf(int which, size_t bytes);
   void release();
 };
 
-Workspace *acquire_ws(const pclmi_tree *t);
-void release_ws(const pclmi_tree *t, Workspace *w);
+// s: the stream the caller is going to use the workspace on (a workspace released with work still in flight on
+// another stream is ordered behind that work with hipStreamWaitEvent)
+Workspace *acquire_ws(const pclmi_tree *t, hipStream_t s);
+void release_ws(const pclmi_tree *t, Workspace *w);                       // the caller has synchronised its stream
+void release_ws_async(const pclmi_tree *t, Workspace *w, hipStream_t s);  // work using w is still queued on s
 struct WsGuard {
   const pclmi_tree *t;
   Workspace *w;
-  explicit WsGuard(const pclmi_tree *tt) : t(tt), w(acquire_ws(tt)) {}
+  WsGuard(const pclmi_tree *tt, hipStream_t s) : t(tt), w(acquire_ws(tt, s)) {}
   ~WsGuard() { release_ws(t, w); }
 };
 
@@ -161,6 +172,13 @@ int launch_morton_order(const pclmi_tree *t, Workspace *w, const float *d_q, siz
 int launch_knn(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, size_t q_stride_f,
                const int32_t *d_order, int k_eff, int32_t *d_idx, float *d_d2, hipStream_t s);
 
+
+// ---- k-NN entry-point plumbing (api_core.hip), shared by pclmi_knn_dev / _async / _noalloc ----
+// knn_check: argument checks, *k_eff = min(k, tree size); knn_enqueue: ordering pass + traversal on s with workspace w
+int knn_check(const pclmi_tree *t, const float *d_q, size_t nq, size_t q_stride_bytes, int k, int32_t *d_idx,
+              float *d_d2, int *k_eff);
+int knn_enqueue(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, size_t q_stride_bytes, int k_eff,
+                int32_t *d_idx, float *d_d2, hipStream_t s);
 
 // ---- small cache of result buffers (api_core.hip): pclmi_free_dev parks, radius search reuses ----
 void *dev_cache_get(size_t bytes);  // nullptr on allocation failure (error text set)

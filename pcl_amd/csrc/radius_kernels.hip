@@ -686,7 +686,7 @@ int pclmi_radius_dev(const pclmi_tree *t, const float *d_q, size_t nq, size_t q_
   PCLMI_HIP(hipSetDevice(t->device));
   hipStream_t s = stream ? (hipStream_t)stream : t->stream;
   const float r2 = (float)(radius * radius);  // impl/kdtree_flann.hpp:140
-  WsGuard g(t);
+  WsGuard g(t, s);
   return radius_search_dev(t, g.w, d_q, nq, q_stride_bytes / 4, r2, max_nn, sorted, d_offsets, d_idx, d_d2, total,
                            s);
 }
