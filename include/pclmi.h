@@ -112,6 +112,20 @@ int pclmi_knn_dev(const pclmi_tree *t, const float *d_queries, size_t nq, size_t
 int pclmi_knn_dev_async(const pclmi_tree *t, const float *d_queries, size_t nq, size_t q_stride_bytes,
                         int k, int32_t *d_idx, float *d_d2, void *stream);
 
+/* Allocation-free variant of pclmi_knn_dev_async.  It has NO counterpart in the reference: it exists for callers
+ * that cannot call hipMalloc - code under HIP graph capture, tight serving loops, harnesses that forbid allocation.
+ * Same kernels and results; the scratch of the query-ordering pass lives in a file-scope device array of the
+ * library (about 21 MB per GPU the library runs on, held until the process ends) instead of pooled hipMalloc'd
+ * buffers, so the call performs no hipMalloc / hipFree and creates no events: it only enqueues on `stream`.
+ * Limits: nq <= PCLMI_NOALLOC_MAX_QUERIES and min(k, tree size) <= PCLMI_NOALLOC_MAX_K, else
+ * PCLMI_ERR_UNSUPPORTED (split the batch, or use pclmi_knn_dev).  Every call on one GPU shares that GPU's array:
+ * calls that overlap on one GPU (different streams or threads) RACE - serialise them on one stream.  The first call
+ * on a device looks the array's address up (hipGetSymbolAddress); make it once before capturing a graph. */
+#define PCLMI_NOALLOC_MAX_QUERIES ((size_t)1 << 20)
+#define PCLMI_NOALLOC_MAX_K 32
+int pclmi_knn_dev_noalloc(const pclmi_tree *t, const float *d_queries, size_t nq, size_t q_stride_bytes,
+                          int k, int32_t *d_idx, float *d_d2, void *stream);
+
 /* Radius search ----------------------------------------------------------------------
  * Replaces pcl::KdTreeFLANN::radiusSearch (impl/kdtree_flann.hpp:115-157) and the batched
  * loops (search.h:412-434).  A neighbour qualifies iff d2 < (float)(radius*radius)
