@@ -44,10 +44,12 @@ typedef enum {
   PCLMI_ERR_HIP = 3,         /* a HIP runtime call failed */
   PCLMI_ERR_OOM = 4,         /* host or device allocation failed */
   PCLMI_ERR_UNSUPPORTED = 5, /* valid request outside what this build implements */
-  PCLMI_ERR_NOT_ENOUGH = 6   /* ICP: fewer than min_correspondences pairs (icp.hpp:103-108) */
+  PCLMI_ERR_NOT_ENOUGH = 6,  /* ICP: fewer than min_correspondences pairs (icp.hpp:103-108) */
+  PCLMI_ERR_COMM = 7         /* multi-GPU exchange: a peer's data did not arrive within the timeout */
 } pclmi_status;
 
 typedef struct pclmi_tree pclmi_tree;
+typedef struct pclmi_comm pclmi_comm; /* multi-GPU exchange, see below */
 
 /* Library / device ------------------------------------------------------------------ */
 const char *pclmi_version(void);
@@ -315,6 +317,59 @@ int pclmi_icp_solve_dev(pclmi_icp_ctx *ctx, const double *d_sums, void *stream);
 int pclmi_icp_run_dev(pclmi_icp_ctx *ctx, double max_correspondence_distance, int iterations,
                       void *stream);
 int pclmi_icp_state(pclmi_icp_ctx *ctx, float final_T[16], pclmi_icp_stats *stats);
+/* Sharded device-resident loop: with a communicator attached, every iteration of pclmi_icp_run_dev is still ONE
+ * kernel per rank - the workgroup that finishes the rank's reduction exchanges the PCLMI_ICP_NSUMS sums with the
+ * peers (pclmi_comm, in rank order) and runs the solve; every rank ends with bit-identical transforms.  All ranks
+ * must run the same number of iterations (the convergence criteria see identical sums, so they stop together).
+ * comm == NULL detaches.  pclmi_icp_state returns PCLMI_ERR_COMM when an exchange timed out. */
+int pclmi_icp_set_comm(pclmi_icp_ctx *ctx, pclmi_comm *comm);
+/* pclmi_icp_begin for rank `rank` of `world`: every rank passes the WHOLE source; it is ordered along the Hilbert
+ * curve once (the same order on every rank) and cut into `world` contiguous runs, so a rank's shard is spatially
+ * compact.  pclmi_icp_shard_size: points of this rank's run.  pclmi_icp_end of such a context writes
+ * only the rank's own rows of `aligned` (n_src x 16 bytes, rows of the whole source). */
+int pclmi_icp_begin_sharded(const pclmi_tree *target, const float *src, size_t n_src, size_t stride_bytes,
+                            const float *guess, int rank, int world, pclmi_icp_ctx **out);
+size_t pclmi_icp_shard_size(const pclmi_icp_ctx *ctx);
+/* pclmi_icp_align over the ranks of `comm` (one process per GPU; every rank calls it with the same arguments and the
+ * whole source): target replicated, source sharded as above, one exchange of the PCLMI_ICP_NSUMS sums per iteration
+ * inside the step kernel.  final_T and stats are bit-identical on every rank; `aligned` (nullable, n_src rows)
+ * receives this rank's own rows only.  RANSAC rejection needs the global pair list: ransac_iterations must be 0
+ * (PCLMI_ERR_UNSUPPORTED otherwise).  A communicator of one rank forwards to pclmi_icp_align. */
+int pclmi_icp_align_sharded(const pclmi_icp_params *p, const pclmi_tree *target, const float *src, size_t n_src,
+                            size_t stride_bytes, const float *guess, pclmi_comm *comm, float final_T[16],
+                            float *aligned, pclmi_icp_stats *stats);
+
+/* Multi-GPU exchange (one process per GPU on one node) -----------------------------------
+ * The reference is single-process (no counterpart); this is the exchange step of the sharded ICP loop
+ * (one all-reduce of the PCLMI_ICP_NSUMS fp64 moments per iteration) kept BELOW the C ABI, so that C++
+ * hosts of the facade can use several GPUs without a Python / torch.distributed driver.  Every rank owns a mailbox in
+ * device memory that every peer maps through HIP IPC (xGMI peer access); an all-reduce is device code that pushes the
+ * values into the peers' mailboxes as 8-byte {sequence tag, payload} granules, waits for theirs and adds in rank order
+ * (identical bits on every rank).  Every wait is bounded: a missing peer yields PCLMI_ERR_COMM, never a
+ * hung GPU.
+ *   pclmi_set_device(local_rank);
+ *   pclmi_comm_begin(rank, world, &comm, my_handle);       allocate + export the mailbox
+ *   [all-gather the PCLMI_COMM_HANDLE_BYTES handles by any means: MPI, torch.distributed, files]
+ *   pclmi_comm_connect(comm, all_handles);                 map the peers' mailboxes
+ * or pclmi_comm_create_shm(rank, world, name, &comm): the same with the handles exchanged through the POSIX
+ * shared-memory object `name` (unique per job; rank 0 creates it).
+ * Every rank must issue the same sequence of exchanges (pclmi_comm_allreduce_f64 calls and ICP iterations of
+ * contexts the communicator is attached to). */
+#define PCLMI_COMM_HANDLE_BYTES 128
+#define PCLMI_COMM_MAX_RANKS 16
+int pclmi_comm_begin(int rank, int world, pclmi_comm **out, unsigned char handle[PCLMI_COMM_HANDLE_BYTES]);
+int pclmi_comm_connect(pclmi_comm *c, const unsigned char *all_handles /* world x PCLMI_COMM_HANDLE_BYTES */);
+int pclmi_comm_create_shm(int rank, int world, const char *name, pclmi_comm **out);
+int pclmi_comm_rank(const pclmi_comm *c);
+int pclmi_comm_size(const pclmi_comm *c);
+/* How long a rank waits for a peer inside a kernel before giving up (default 10 s). */
+int pclmi_comm_set_timeout(pclmi_comm *c, double seconds);
+/* In-place sum over the ranks of d_buf[0..count) (device memory, count <= 32), enqueued on `stream` as ONE
+ * one-workgroup kernel.  pclmi_comm_status synchronises the device and reports PCLMI_ERR_COMM if any exchange of
+ * this communicator timed out. */
+int pclmi_comm_allreduce_f64(pclmi_comm *c, double *d_buf, int count, void *stream);
+int pclmi_comm_status(pclmi_comm *c);
+void pclmi_comm_destroy(pclmi_comm *c);
 
 /* Surface normals ----------------------------------------------------------------------
  * The largest caller of the batched searches.  Replaces

@@ -11,7 +11,7 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "lib" / "libpclmi.so"
 _LIB = None
 
-STATUS = {0: "OK", 1: "INVALID", 2: "NO_DEVICE", 3: "HIP", 4: "OOM", 5: "UNSUPPORTED", 6: "NOT_ENOUGH"}
+STATUS = {0: "OK", 1: "INVALID", 2: "NO_DEVICE", 3: "HIP", 4: "OOM", 5: "UNSUPPORTED", 6: "NOT_ENOUGH", 7: "COMM"}
 ICP_NSUMS = 24
 
 CORR_DTYPE = np.dtype([("index_query", np.int32), ("index_match", np.int32), ("distance", np.float32)])
@@ -124,7 +124,23 @@ SIGNATURES = {
     "pclmi_icp_solve_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "pclmi_icp_run_dev": (C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_void_p]),
     "pclmi_icp_state": (C.c_int, [C.c_void_p, c_f32p, C.POINTER(IcpStats)]),
+    "pclmi_icp_set_comm": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pclmi_icp_begin_sharded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, c_f32p, C.c_int, C.c_int,
+                                          C.POINTER(C.c_void_p)]),
+    "pclmi_icp_shard_size": (C.c_size_t, [C.c_void_p]),
+    "pclmi_icp_align_sharded": (C.c_int, [C.POINTER(IcpParams), C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t,
+                                          c_f32p, C.c_void_p, c_f32p, C.c_void_p, C.POINTER(IcpStats)]),
+    "pclmi_comm_begin": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_void_p]),
+    "pclmi_comm_connect": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pclmi_comm_create_shm": (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]),
+    "pclmi_comm_rank": (C.c_int, [C.c_void_p]),
+    "pclmi_comm_size": (C.c_int, [C.c_void_p]),
+    "pclmi_comm_set_timeout": (C.c_int, [C.c_void_p, C.c_double]),
+    "pclmi_comm_allreduce_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "pclmi_comm_status": (C.c_int, [C.c_void_p]),
+    "pclmi_comm_destroy": (None, [C.c_void_p]),
 }
+COMM_HANDLE_BYTES = 128
 
 
 def _share_hip_runtime_with_torch():
@@ -211,9 +227,12 @@ class Tree:
                                      None if idx is None else idx.ctypes.data, 0 if idx is None else len(idx), 0,
                                      C.byref(h)))
         self.h = h
+        self._shards = 0  # live IcpShard contexts holding a raw pointer to this tree
 
     def close(self):
         if getattr(self, "h", None):
+            if getattr(self, "_shards", 0) > 0:
+                raise PclmiError(1, "Tree.close() while %d ICP context(s) still use the tree" % self._shards)
             load_library().pclmi_tree_destroy(self.h)
             self.h = None
 
@@ -452,6 +471,24 @@ def icp_align(target_tree, src, params=None, guess=None):
     return rc, T.reshape(4, 4), out, st
 
 
+def icp_align_sharded(target_tree, src, comm, params=None, guess=None):
+    """pclmi_icp_align_sharded: every rank passes the whole source.  Returns (status, T, aligned, stats); `aligned`
+    holds this rank's own rows (the other rows are NaN)."""
+    lib = load_library()
+    s = _pts(src)
+    p = params or icp_default_params()
+    T = np.zeros(16, np.float32)
+    out = np.full((len(s), 4), np.nan, np.float32)
+    st = IcpStats()
+    g = None if guess is None else np.ascontiguousarray(guess, np.float32).reshape(16)
+    rc = lib.pclmi_icp_align_sharded(C.byref(p), target_tree.h, s.ctypes.data, len(s), s.shape[1] * 4,
+                                     None if g is None else g.ctypes.data_as(c_f32p), comm.h, T.ctypes.data_as(c_f32p),
+                                     out.ctypes.data, C.byref(st))
+    if rc not in (0, 6):
+        _check(rc)
+    return rc, T.reshape(4, 4), out, st
+
+
 def fitness_score(target_tree, src, T, max_range=float(np.finfo(np.float64).max)):
     s = _pts(src)
     Tm = np.ascontiguousarray(T, np.float32).reshape(16)
@@ -470,18 +507,88 @@ def icp_solve(sums):
     return T.reshape(4, 4)
 
 
+class Comm:
+    """pclmi_comm: the multi-GPU exchange below the C ABI (one process per GPU, peer mailboxes over HIP IPC).
+
+    Comm.from_shm(rank, world, name) exchanges the mailbox handles through a POSIX shared-memory object;
+    Comm.from_allgather(rank, world, allgather) takes any callable bytes -> list of every rank's bytes
+    (torch.distributed.all_gather_object, MPI ...)."""
+
+    def __init__(self, handle):
+        self.h = handle
+
+    @classmethod
+    def from_shm(cls, rank, world, name):
+        h = C.c_void_p()
+        _check(load_library().pclmi_comm_create_shm(rank, world, name.encode(), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_allgather(cls, rank, world, allgather):
+        lib = load_library()
+        h = C.c_void_p()
+        mine = (C.c_ubyte * COMM_HANDLE_BYTES)()
+        _check(lib.pclmi_comm_begin(rank, world, C.byref(h), mine))
+        every = allgather(bytes(mine))
+        assert len(every) == world and all(len(b) == COMM_HANDLE_BYTES for b in every)
+        if world > 1:
+            blob = b"".join(every)
+            _check(lib.pclmi_comm_connect(h, blob))
+        return cls(h)
+
+    @property
+    def rank(self):
+        return load_library().pclmi_comm_rank(self.h)
+
+    @property
+    def size(self):
+        return load_library().pclmi_comm_size(self.h)
+
+    def set_timeout(self, seconds):
+        _check(load_library().pclmi_comm_set_timeout(self.h, float(seconds)))
+
+    def allreduce_f64(self, buf_ptr, count, stream=None):
+        _check(load_library().pclmi_comm_allreduce_f64(self.h, buf_ptr, count, stream))
+
+    def status(self):
+        """Synchronises the device; raises PclmiError(COMM) if an exchange timed out."""
+        _check(load_library().pclmi_comm_status(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            load_library().pclmi_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class IcpShard:
     """Per-rank ICP context for the sharded driver (pclmi_icp_begin / step / set_transform / end)."""
 
-    def __init__(self, target_tree, src, guess=None):
+    def __init__(self, target_tree, src, guess=None, rank=0, world=1):
+        """world > 1: `src` is the WHOLE source; the context keeps rank's contiguous run of its Hilbert order
+        (pclmi_icp_begin_sharded) and end() returns the whole-size array with only that run's rows written."""
         lib = load_library()
         self.src = _pts(src)
         g = None if guess is None else np.ascontiguousarray(guess, np.float32).reshape(16)
         h = C.c_void_p()
-        _check(lib.pclmi_icp_begin(target_tree.h, self.src.ctypes.data, len(self.src), self.src.shape[1] * 4,
-                                   None if g is None else g.ctypes.data_as(c_f32p), C.byref(h)))
+        _check(lib.pclmi_icp_begin_sharded(target_tree.h, self.src.ctypes.data, len(self.src), self.src.shape[1] * 4,
+                                           None if g is None else g.ctypes.data_as(c_f32p), rank, world, C.byref(h)))
         self.h = h
         self.n = len(self.src)
+        self.shard_size = lib.pclmi_icp_shard_size(h)
+        self.tree = target_tree  # the C context holds a raw pointer to the tree: keep it alive as long as the shard
+        target_tree._shards += 1
+        self.comm = None
+
+    def set_comm(self, comm):
+        """Attach a Comm: run_dev then exchanges the sums inside the step kernel (pclmi_icp_set_comm)."""
+        _check(load_library().pclmi_icp_set_comm(self.h, None if comm is None else comm.h))
+        self.comm = comm
 
     def step(self, max_correspondence_distance):
         sums = np.zeros(ICP_NSUMS, np.float64)
@@ -510,19 +617,21 @@ class IcpShard:
         T = np.zeros(16, np.float32)
         st = IcpStats()
         rc = load_library().pclmi_icp_state(self.h, T.ctypes.data_as(c_f32p), C.byref(st))
-        if rc not in (0, 6):
+        if rc not in (0, 6, 7):
             _check(rc)
         return rc, T.reshape(4, 4), st
 
     def end(self, want_aligned=True):
         out = np.zeros((self.n, 4), np.float32) if want_aligned else None
         h, self.h = self.h, None
+        self.tree._shards -= 1
         _check(load_library().pclmi_icp_end(h, None if out is None else out.ctypes.data))
         return out
 
     def __del__(self):
         if getattr(self, "h", None):
             try:
+                self.tree._shards -= 1
                 load_library().pclmi_icp_end(self.h, None)
             except Exception:
                 pass

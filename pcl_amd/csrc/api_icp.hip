@@ -56,6 +56,10 @@ struct pclmi_icp_ctx {
   DevBuf<float> dist;     // per slot: min(d2, thr2) of the previous step (correspondence_distances_)
   DevBuf<double> partials;
   DevBuf<double> sums;
+  DevBuf<double> gpart;          // group sums of the step kernel's tail
+  DevBuf<unsigned int> tickets;  // [groups] group tickets, then the launch ticket
+  unsigned groups = 1;
+  pclmi_comm *comm = nullptr;    // exchange partner of pclmi_icp_run_dev (pclmi_icp_set_comm)
   double origin[3] = {0, 0, 0};
   bool pending = false;   // a transform waits to be applied by the next step / by end()
   float T[16];
@@ -65,6 +69,10 @@ struct pclmi_icp_ctx {
   bool stepped = false;       // nn holds the neighbours of a previous step
   DevBuf<IcpDevState> state;  // device-resident loop state (pclmi_icp_solve_dev)
   bool dev_mode = false;      // the transform chain lives in `state`, not in T / pending
+  // sharded contexts (pclmi_icp_begin_sharded): this rank's contiguous run of the Hilbert-ordered source
+  bool sharded = false;
+  size_t n_full = 0;                // rows of the whole source
+  std::vector<int> shard_rows;      // slot -> row of the whole source
 };
 
 extern "C" {
@@ -199,8 +207,17 @@ int pclmi_correspondences_reciprocal(const pclmi_tree *target, const pclmi_tree 
 // ---- sharded ICP steps ---------------------------------------------------------------------
 int pclmi_icp_begin(const pclmi_tree *target, const float *src, size_t n_src, size_t stride_bytes,
                     const float *guess, pclmi_icp_ctx **out) {
+  return pclmi_icp_begin_sharded(target, src, n_src, stride_bytes, guess, 0, 1, out);
+}
+
+// The whole source is ordered along the Hilbert curve once (every rank computes the same order), then cut into
+// `world` contiguous runs: a rank's shard is spatially compact, so its searches touch one part of the target tree
+// (SURVEY 8e).  world == 1: the plain context.
+int pclmi_icp_begin_sharded(const pclmi_tree *target, const float *src, size_t n_src, size_t stride_bytes,
+                            const float *guess, int rank, int world, pclmi_icp_ctx **out) {
   PCLMI_CHECK(target && out, PCLMI_ERR_INVALID, "NULL argument");
   *out = nullptr;
+  PCLMI_CHECK(world >= 1 && rank >= 0 && rank < world, PCLMI_ERR_INVALID, "rank %d of %d", rank, world);
   PCLMI_CHECK(n_src == 0 || src, PCLMI_ERR_INVALID, "src is NULL");
   PCLMI_CHECK(stride_bytes >= 12 && stride_bytes % 4 == 0, PCLMI_ERR_INVALID, "bad stride %zu", stride_bytes);
   PCLMI_CHECK(n_src < ((size_t)1 << 31), PCLMI_ERR_UNSUPPORTED, "more than 2^31-1 source points");
@@ -241,6 +258,10 @@ int pclmi_icp_begin(const pclmi_tree *target, const float *src, size_t n_src, si
       (rc = c->partials.alloc((size_t)std::max(icp_step_blocks(n_src), pair_reduce_blocks(n_src)) * PCLMI_ICP_NSUMS)) ||
       (rc = c->sums.alloc(PCLMI_ICP_NSUMS)))
     return fail(rc);
+  c->groups = icp_step_groups(n_src);
+  if ((rc = c->gpart.alloc((size_t)c->groups * PCLMI_ICP_NSUMS)) || (rc = c->tickets.alloc(c->groups + 1))) return fail(rc);
+  if (hipMemsetAsync(c->tickets.p, 0, (c->groups + 1) * sizeof(unsigned int), c->stream) != hipSuccess)
+    return fail(hip_fail(hipGetLastError(), "memset", __FILE__, __LINE__));
   {
     WsGuard g(target, c->stream);
     const int32_t *d_order = nullptr;
@@ -256,9 +277,26 @@ int pclmi_icp_begin(const pclmi_tree *target, const float *src, size_t n_src, si
     if (hipStreamSynchronize(c->stream) != hipSuccess)
       return fail(hip_fail(hipGetLastError(), "sync", __FILE__, __LINE__));
   }
-  launch_permute(raw.p, c->order.p, n_src, c->pts.p, c->stream);
-  // inv[order[slot]] = slot
-  {
+  c->n_full = n_src;
+  if (world > 1) {
+    // this rank's contiguous run of the ordered source
+    const size_t per = (n_src + (size_t)world - 1) / (size_t)world;
+    const size_t lo = std::min(n_src, per * (size_t)rank), hi = std::min(n_src, lo + per);
+    c->sharded = true;
+    c->n = hi - lo;
+    c->shard_rows.resize(c->n);
+    if (c->n) {
+      // on the context's stream (a non-blocking stream is not ordered against the null stream's copies)
+      if (hipMemcpyAsync(c->shard_rows.data(), c->order.p + lo, c->n * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+          hipStreamSynchronize(c->stream) != hipSuccess ||
+          (lo && hipMemcpyAsync(c->order.p, c->order.p + lo, c->n * 4, hipMemcpyDeviceToDevice, c->stream) != hipSuccess))
+        return fail(hip_fail(hipGetLastError(), "shard cut", __FILE__, __LINE__));
+    }
+    c->groups = icp_step_groups(c->n);  // buffers were sized for the whole source: large enough
+  }
+  launch_permute(raw.p, c->order.p, c->n, c->pts.p, c->stream);
+  // inv[order[slot]] = slot (RANSAC pair lists; single-process contexts only)
+  if (!c->sharded) {
     DevBuf<int> ids;
     if ((rc = ids.alloc(n_src))) return fail(rc);
     launch_iota(ids.p, n_src, c->stream);
@@ -271,7 +309,7 @@ int pclmi_icp_begin(const pclmi_tree *target, const float *src, size_t n_src, si
     if (n_src && hipMemcpy(c->inv.p, h_inv.data(), n_src * 4, hipMemcpyHostToDevice) != hipSuccess)
       return fail(hip_fail(hipGetLastError(), "inv upload", __FILE__, __LINE__));
   }
-  if (n_src && hipMemsetAsync(c->dist.p, 0, n_src * 4, c->stream) != hipSuccess)  // previous distances start at 0
+  if (c->n && hipMemsetAsync(c->dist.p, 0, c->n * 4, c->stream) != hipSuccess)  // previous distances start at 0
     return fail(hip_fail(hipGetLastError(), "memset", __FILE__, __LINE__));
   // moments are taken about the centre of the target's bounding box: identical on every rank
   for (int d = 0; d < 3; ++d) c->origin[d] = 0.5 * ((double)target->bb_lo[d] + (double)target->bb_hi[d]);
@@ -295,16 +333,27 @@ int pclmi_icp_begin(const pclmi_tree *target, const float *src, size_t n_src, si
   return PCLMI_OK;
 }
 
+// fused: the launch's last workgroup also exchanges the sums with the other ranks (when a communicator is attached)
+// and runs the solve; otherwise it only leaves the rank's sums in d_sums
 static int icp_step_enqueue(pclmi_icp_ctx *c, double max_correspondence_distance, double *d_sums, void *stream,
-                            bool fuse_solve) {
+                            bool fused) {
   PCLMI_CHECK(c && d_sums, PCLMI_ERR_INVALID, "NULL argument");
   PCLMI_HIP(hipSetDevice(c->tree->device));
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
   c->user_stream = stream ? s : nullptr;
   const double thr2 = max_correspondence_distance * max_correspondence_distance;  // icp.hpp:57
   c->last_thr2 = thr2;
+  IcpTail tail;
+  tail.gpart = c->gpart.p;
+  tail.gticket = c->tickets.p;
+  tail.ticket = c->tickets.p + c->groups;
+  tail.sums_out = d_sums;
+  tail.st = c->dev_mode ? c->state.p : nullptr;
+  tail.solve = fused ? 1 : 0;
+  tail.ngroups = (int)c->groups;
+  if (fused && c->comm) tail.comm = comm_view(c->comm);
   launch_icp_step(c->tree, c->pts.p, c->n, c->pending, make_xf(c->T), thr2, c->nn.p, c->nn_slot.p, c->dist.p, c->origin,
-                  c->partials.p, d_sums, s, c->dev_mode ? c->state.p : nullptr, c->stepped, fuse_solve);
+                  c->partials.p, s, c->dev_mode ? c->state.p : nullptr, c->stepped, tail);
   c->pending = false;
   c->stepped = true;
   PCLMI_HIP(hipGetLastError());
@@ -357,10 +406,19 @@ int pclmi_icp_run_dev(pclmi_icp_ctx *c, double max_correspondence_distance, int 
   PCLMI_CHECK(!c->pending, PCLMI_ERR_INVALID,
               "pclmi_icp_run_dev after pclmi_icp_set_transform: one context is driven either from the host or "
               "from the device");
-  // single-GPU loop: nothing sits between the reduction and the solve, so they share one launch
-  // (reduce_solve_kernel); per iteration: step kernel -> reduce + solve
+  // ONE launch per iteration: the step kernel's last workgroup sums the block partials, exchanges the sums with the
+  // other ranks when a communicator is attached, and runs the solve (icp_kernels.hip icp_step_tail)
   c->dev_mode = true;
   for (int i = 0; i < iterations; ++i) RC(icp_step_enqueue(c, max_correspondence_distance, c->sums.p, stream, true));
+  return PCLMI_OK;
+}
+
+int pclmi_icp_set_comm(pclmi_icp_ctx *c, pclmi_comm *comm) {
+  PCLMI_CHECK(c, PCLMI_ERR_INVALID, "NULL argument");
+  PCLMI_CHECK(!comm || comm_device(comm) == c->tree->device, PCLMI_ERR_INVALID,
+              "the communicator lives on device %d, the context on device %d", comm ? comm_device(comm) : -1,
+              c->tree->device);
+  c->comm = (comm && pclmi_comm_size(comm) > 1) ? comm : nullptr;
   return PCLMI_OK;
 }
 
@@ -379,6 +437,10 @@ int pclmi_icp_state(pclmi_icp_ctx *c, float final_T[16], pclmi_icp_stats *stats)
     stats->last_inliers = h.last_pairs;
     stats->fitness_delta = h.fit;
     stats->transform_delta = h.tdelta;
+  }
+  if (h.status == PCLMI_ERR_COMM) {
+    set_error("the exchange with the other ranks timed out in iteration %d", h.iterations + 1);
+    return PCLMI_ERR_COMM;
   }
   if (h.status == PCLMI_ERR_NOT_ENOUGH) {
     set_error("not enough correspondences (%d < the configured minimum): relax the threshold parameters",
@@ -409,7 +471,17 @@ int pclmi_icp_end(pclmi_icp_ctx *c, float *aligned) {
   int rc = PCLMI_OK;
   (void)hipSetDevice(c->tree->device);
   if (c->user_stream) (void)hipStreamSynchronize(c->user_stream);  // steps enqueued on the caller's stream
-  if (aligned && c->n) {
+  if (aligned && c->n && c->sharded) {
+    // own rows only, at their positions in the whole source (the other rows belong to other ranks)
+    if (c->pending) launch_transform(c->pts.p, c->n, make_xf(c->T), c->stream);
+    if (c->dev_mode) launch_transform_pending(c->pts.p, c->n, c->state.p, c->stream);
+    std::vector<float4> h(c->n);
+    hipError_t e = hipMemcpyAsync(h.data(), c->pts.p, c->n * sizeof(float4), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) rc = hip_fail(e, "aligned download", __FILE__, __LINE__);
+    else
+      for (size_t i = 0; i < c->n; ++i) std::memcpy(aligned + (size_t)c->shard_rows[i] * 4, &h[i], sizeof(float4));
+  } else if (aligned && c->n) {
     if (c->pending) launch_transform(c->pts.p, c->n, make_xf(c->T), c->stream);
     if (c->dev_mode) launch_transform_pending(c->pts.p, c->n, c->state.p, c->stream);
     DevBuf<float4> outb;
@@ -425,6 +497,39 @@ int pclmi_icp_end(pclmi_icp_ctx *c, float *aligned) {
   }
   delete c;
   return rc;
+}
+
+size_t pclmi_icp_shard_size(const pclmi_icp_ctx *c) { return c ? c->n : 0; }
+
+int pclmi_icp_align_sharded(const pclmi_icp_params *p, const pclmi_tree *target, const float *src, size_t n_src,
+                            size_t stride_bytes, const float *guess, pclmi_comm *comm, float final_T[16],
+                            float *aligned, pclmi_icp_stats *stats) {
+  PCLMI_CHECK(p && target && final_T && comm, PCLMI_ERR_INVALID, "NULL argument");
+  set_identity(final_T);
+  if (stats) std::memset(stats, 0, sizeof(*stats));
+  PCLMI_CHECK(n_src > 0 && src, PCLMI_ERR_INVALID, "empty source cloud");
+  PCLMI_CHECK(p->ransac_iterations <= 0 || pclmi_comm_size(comm) == 1, PCLMI_ERR_UNSUPPORTED,
+              "the RANSAC rejection step needs the global pair list: set ransac_iterations = 0 for a sharded align");
+  if (pclmi_comm_size(comm) == 1) return pclmi_icp_align(p, target, src, n_src, stride_bytes, guess, final_T, aligned, stats);
+  pclmi_icp_ctx *c = nullptr;
+  RC(pclmi_icp_begin_sharded(target, src, n_src, stride_bytes, guess, pclmi_comm_rank(comm), pclmi_comm_size(comm), &c));
+  if (guess && !is_identity(guess)) std::memcpy(final_T, guess, 16 * sizeof(float));
+  int rc = pclmi_icp_set_criteria(c, p);
+  if (!rc) rc = pclmi_icp_set_comm(c, comm);
+  pclmi_icp_stats st;
+  std::memset(&st, 0, sizeof(st));
+  int enqueued = 0;
+  while (!rc) {
+    // every rank enqueues the same chunks: the criteria see identical sums, so all ranks stop in the same iteration
+    const int chunk = std::max(1, std::min(16, p->max_iterations - enqueued));
+    if ((rc = pclmi_icp_run_dev(c, p->max_correspondence_distance, chunk, nullptr))) break;
+    enqueued += chunk;
+    rc = pclmi_icp_state(c, final_T, &st);
+    if (st.converged) break;
+  }
+  if (stats) *stats = st;
+  int rc2 = pclmi_icp_end(c, aligned);
+  return rc ? rc : rc2;
 }
 
 // ---- RANSAC rejection as invoked from ICP (icp.hpp:113-150) ------------------------------------

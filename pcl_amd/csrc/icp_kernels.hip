@@ -14,6 +14,7 @@
 // neighbours and the loads/stores of the point array are fully coalesced.
 #include <hipcub/hipcub.hpp>
 
+#include "comm_dev.hpp"
 #include "pclmi_internal.h"
 #include "rigid_solve.hpp"
 #include "traverse.hpp"
@@ -129,6 +130,154 @@ __device__ __forceinline__ void wave_reduce_to_row(double (&v)[8], bool use, dou
 constexpr int NS = PCLMI_ICP_NSUMS;  // 24
 constexpr int ICP_WPB = 4;
 
+// One lane turns the (all-reduced) sums into the next transform and evaluates the convergence criteria
+// (icp.hpp:103-108,171-196): the device-side twin of the loop body of pclmi_icp_align.
+__device__ __forceinline__ void icp_solve_body(const double *__restrict__ sums, IcpDevState *__restrict__ st) {
+  const double *h = sums;
+  const long long cnt = llround(h[0]);
+  st->last_pairs = (int)cnt;
+  if (cnt < (long long)st->min_correspondences) {  // icp.hpp:103-108
+    st->status = PCLMI_ERR_NOT_ENOUGH;
+    st->done = 1;
+    return;
+  }
+  float Tprev[16], T[16], F[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    Tprev[i] = st->T[i];
+    F[i] = st->final_T[i];
+  }
+  if (!rs::solve_from_sums(h, T)) {
+    st->status = PCLMI_ERR_NOT_ENOUGH;
+    st->done = 1;
+    return;
+  }
+  rs::mat4_mul(T, F, F);  // icp.hpp:177
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    st->T[i] = T[i];
+    st->final_T[i] = F[i];
+  }
+  st->apply = 1;  // icp.hpp:174, carried out by the next step (or at the end)
+  const int it = st->iterations + 1;
+  st->iterations = it;
+  const double tdelta = (double)rs::transform_delta(T, Tprev);
+  const double n_points = h[18] > 0 ? h[18] : 1.0;
+  const double fit = h[17] / n_points;  // registration.hpp:60-68
+  st->tdelta = tdelta;
+  st->fit = fit;
+  if (it >= st->max_iterations || tdelta < st->transformation_epsilon ||
+      fabs(fit) <= st->euclidean_fitness_epsilon) {  // icp.hpp:193-196
+    st->converged = 1;
+    st->done = 1;
+  }
+}
+
+
+// agent-scope (sc1) accesses in the global address space: how workgroups of one launch hand data to each other
+// without cache maintenance (MI355X_MICROARCH.md, "Valid forms": every store and every load of the handed-off bytes
+// sc1, the storing waves drain their stores, one lane then signals with an agent-scope atomic add)
+typedef __attribute__((address_space(1))) double *g_f64p;
+typedef __attribute__((address_space(1))) const double *g_cf64p;
+typedef __attribute__((address_space(1))) unsigned int *g_u32p;
+__device__ __forceinline__ void st_agent(double *p, double v) {
+  __hip_atomic_store((g_f64p)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_agent(const double *p) {
+  return __hip_atomic_load((g_cf64p)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// What the workgroup that finishes a step's reduction goes on to do (IcpTail, see icp_step_tail).
+constexpr int ICP_GROUP = 64;  // workgroups per reduction group
+
+// Sum of column `col` over `cnt` entries spaced 1 apart, by the 8 lanes of one aligned lane group (r = lane & 7):
+// entries r, r + 8, ... in ascending order, then a fixed butterfly.  The order depends on cnt only.
+__device__ __forceinline__ double tail_column_sum(const double *col_base, int cnt, int r, bool active) {
+  double s = 0.0;
+  if (active)
+    for (int i = r; i < cnt; i += 8) s += ld_agent(col_base + i);
+  s += __shfl_xor(s, 4);
+  s += __shfl_xor(s, 2);
+  s += __shfl_xor(s, 1);
+  return s;
+}
+
+// Tail of the step kernel: the block partials become the NS sums of the launch WITHOUT another kernel.
+// Two levels of arrival tickets: the workgroup that arrives last in its group of ICP_GROUP adds up the group's
+// partials; the group that finishes last adds up the group sums (fixed order: the result does not depend on which
+// workgroup happens to be last), exchanges them with the other ranks when a communicator is attached (comm_dev.hpp),
+// writes sums_out and, when asked, runs the solve.  Nobody waits for anybody inside the GPU: a workgroup that is not
+// last simply ends.  Returns to the caller only in the last workgroup's first wave... never: everything happens here.
+__device__ __forceinline__ void icp_step_tail(const IcpTail &tail, double *__restrict__ partials, double (*lds)[NS]) {
+  __shared__ int s_last;
+  __shared__ double fin[NS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int nblk = gridDim.x;
+  if (tid < NS) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < ICP_WPB; ++w) s += lds[w][tid];
+    // column-major (sum j of block b at [j * blocks + b]): a group's entries of one column are contiguous
+    st_agent(&partials[(size_t)tid * nblk + blockIdx.x], s);
+  }
+  drain_stores();
+  __syncthreads();
+  const int g = blockIdx.x / ICP_GROUP;
+  const int gsize = min(ICP_GROUP, nblk - g * ICP_GROUP);
+  if (tid == 0) {
+    const unsigned int t = __hip_atomic_fetch_add((g_u32p)&tail.gticket[g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (t == (unsigned int)(gsize - 1)) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  const int col = tid >> 3, r = tid & 7;
+  const bool colth = tid < NS * 8;
+  {
+    const double s = tail_column_sum(partials + (size_t)(colth ? col : 0) * nblk + (size_t)g * ICP_GROUP, gsize, r, colth);
+    if (colth && r == 0) st_agent(&tail.gpart[(size_t)col * tail.ngroups + g], s);
+  }
+  drain_stores();
+  __syncthreads();
+  if (tid == 0) {
+    __hip_atomic_store((g_u32p)&tail.gticket[g], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
+    const unsigned int t = __hip_atomic_fetch_add((g_u32p)tail.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (t == (unsigned int)(tail.ngroups - 1)) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  {
+    const double s = tail_column_sum(tail.gpart + (size_t)(colth ? col : 0) * tail.ngroups, tail.ngroups, r, colth);
+    if (colth && r == 0) fin[col] = s;
+  }
+  __syncthreads();
+  if (tid >= 64) return;  // the first wave goes on alone
+  double v = lane < NS ? fin[lane] : 0.0;
+  bool ok = true;
+  if (tail.comm.world > 1) {
+    const unsigned int seq = *tail.comm.seq + 1u;
+    ok = comm_allreduce_wave(tail.comm, v, NS, lane, seq);
+    if (lane == 0) *tail.comm.seq = seq;
+  }
+  if (lane < NS) {
+    tail.sums_out[lane] = v;  // read by later launches / the host only: a plain store
+    fin[lane] = v;
+  }
+  if (lane == 0) {
+    __hip_atomic_store((g_u32p)tail.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    IcpDevState *st = tail.st;
+    if (st) {
+      st->apply = 0;  // this launch has consumed the pending transform
+      if (!ok) {
+        st->status = PCLMI_ERR_COMM;
+        st->done = 1;
+      } else if (tail.solve) {
+        icp_solve_body(fin, st);
+      }
+    }
+  }
+}
+
 // One ICP iteration over the (Morton-ordered) source points.  See file header.
 // LANE: per-lane traversal (traverse.hpp lane_nearest) with `levels` rows of LDS per wave, started from the
 // distance to the previous step's neighbour (nn_slot, when have_prev) below the wave's common subtree;
@@ -140,7 +289,7 @@ __global__ __launch_bounds__(64 * ICP_WPB) __attribute__((amdgpu_waves_per_eu(8,
                                                                  float *__restrict__ dist, double ox, double oy,
                                                                  double oz, double *__restrict__ partials,
                                                                  const IcpDevState *__restrict__ st, int levels,
-                                                                 int have_prev) {
+                                                                 int have_prev, IcpTail tail) {
   extern __shared__ float far_lds[];
   __shared__ double lds[ICP_WPB][NS];
   if (st) {  // device-resident loop: the pending transform and the stop flag live in device memory
@@ -223,13 +372,7 @@ __global__ __launch_bounds__(64 * ICP_WPB) __attribute__((amdgpu_waves_per_eu(8,
     wave_reduce_to_row(v, counted, &lds[wib][16], lane);
   }
   __syncthreads();
-  if (threadIdx.x < NS) {
-    double s = 0.0;
-#pragma unroll
-    for (int w = 0; w < ICP_WPB; ++w) s += lds[w][threadIdx.x];
-    // column-major (sum j of block b at [j * blocks + b]): the reduction pass reads each column as one contiguous run
-    partials[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = s;
-  }
+  icp_step_tail(tail, partials, lds);
 }
 
 // fixed-order sum of one column of block partials by one workgroup of 256: element r of column j sits at
@@ -248,97 +391,18 @@ __device__ __forceinline__ double column_sum(const double *__restrict__ partials
 }
 
 // block j of the grid produces out[j]
-// st (nullable): the step before this pass has consumed the pending transform of the device state
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const double *__restrict__ partials, int nrows,
                                                               size_t row_stride, size_t col_stride,
-                                                              double *__restrict__ out,
-                                                              IcpDevState *__restrict__ st = nullptr) {
+                                                              double *__restrict__ out) {
   __shared__ double sh[256];
   const int j = blockIdx.x;
-  if (st) {
-    if (st->done) return;  // block-uniform
-    if (j == 0 && threadIdx.x == 0) st->apply = 0;
-  }
   const double s = column_sum(partials, nrows, row_stride, col_stride, j, sh);
   if (threadIdx.x == 0) out[j] = s;
-}
-
-// One lane turns the (all-reduced) sums into the next transform and evaluates the convergence criteria
-// (icp.hpp:103-108,171-196): the device-side twin of the loop body of pclmi_icp_align.
-__device__ __forceinline__ void icp_solve_body(const double *__restrict__ sums, IcpDevState *__restrict__ st) {
-  double h[NS];
-#pragma unroll
-  for (int j = 0; j < NS; ++j) h[j] = sums[j];
-  const long long cnt = llround(h[0]);
-  st->last_pairs = (int)cnt;
-  if (cnt < (long long)st->min_correspondences) {  // icp.hpp:103-108
-    st->status = PCLMI_ERR_NOT_ENOUGH;
-    st->done = 1;
-    return;
-  }
-  float Tprev[16], T[16], F[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    Tprev[i] = st->T[i];
-    F[i] = st->final_T[i];
-  }
-  if (!rs::solve_from_sums(h, T)) {
-    st->status = PCLMI_ERR_NOT_ENOUGH;
-    st->done = 1;
-    return;
-  }
-  rs::mat4_mul(T, F, F);  // icp.hpp:177
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    st->T[i] = T[i];
-    st->final_T[i] = F[i];
-  }
-  st->apply = 1;  // icp.hpp:174, carried out by the next step (or at the end)
-  const int it = st->iterations + 1;
-  st->iterations = it;
-  const double tdelta = (double)rs::transform_delta(T, Tprev);
-  const double n_points = h[18] > 0 ? h[18] : 1.0;
-  const double fit = h[17] / n_points;  // registration.hpp:60-68
-  st->tdelta = tdelta;
-  st->fit = fit;
-  if (it >= st->max_iterations || tdelta < st->transformation_epsilon ||
-      fabs(fit) <= st->euclidean_fitness_epsilon) {  // icp.hpp:193-196
-    st->converged = 1;
-    st->done = 1;
-  }
 }
 
 __global__ __launch_bounds__(64) void icp_solve_kernel(const double *__restrict__ sums, IcpDevState *__restrict__ st) {
   if (threadIdx.x != 0 || st->done) return;
   icp_solve_body(sums, st);
-}
-
-// Single-GPU loop: nothing sits between the column sums and the solve, so they share ONE launch - the block that
-// finishes last (a ticket counter in the device state) runs the solve on the sums the others have published.
-__global__ __launch_bounds__(256) void reduce_solve_kernel(const double *__restrict__ partials, int nrows,
-                                                           size_t row_stride, size_t col_stride,
-                                                           double *__restrict__ out, IcpDevState *__restrict__ st) {
-  __shared__ double sh[256];
-  __shared__ int is_last;
-  const int j = blockIdx.x;
-  if (st->done) return;  // block-uniform: `done` only changes in the solve, after every block has passed here
-  const double s = column_sum(partials, nrows, row_stride, col_stride, j, sh);
-  if (threadIdx.x == 0) {
-    out[j] = s;
-    __threadfence();  // publish out[j] device-wide before taking a ticket
-    const unsigned int t = atomicAdd(&st->ticket, 1u);
-    is_last = (t == gridDim.x - 1) ? 1 : 0;
-  }
-  __syncthreads();
-  if (is_last && threadIdx.x == 0) {
-    __threadfence();  // acquire: the other blocks' sums
-    st->ticket = 0;   // ready for the next iteration's launch
-    st->apply = 0;    // the step before this pass has consumed the pending transform
-    double h[NS];
-#pragma unroll
-    for (int i = 0; i < NS; ++i) h[i] = __hip_atomic_load(&out[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    icp_solve_body(h, st);
-  }
 }
 
 __global__ void transform_pending_kernel(float4 *__restrict__ pts, int n, const IcpDevState *__restrict__ st) {
@@ -533,33 +597,27 @@ void launch_unpermute(const float4 *in, const int *order, size_t n, float4 *out,
 unsigned icp_step_blocks(size_t n) {
   unsigned waves = (unsigned)((n + 63) / 64);
   unsigned blocks = (waves + ICP_WPB - 1) / ICP_WPB;
-  return (blocks + 7) & ~7u;
+  blocks = (blocks + 7) & ~7u;
+  return blocks ? blocks : 8u;  // an empty shard still launches: its sums are zeros, its tail runs the exchange
 }
+
+unsigned icp_step_groups(size_t n) { return (icp_step_blocks(n) + ICP_GROUP - 1) / ICP_GROUP; }
 
 void launch_icp_step(const pclmi_tree *t, float4 *d_pts, size_t n, bool apply, const Xf &T, double thr2,
                      int *d_nn, int *d_nn_slot, float *d_dist, const double origin[3], double *d_partials,
-                     double *d_sums, hipStream_t s, IcpDevState *st, bool have_prev, bool fuse_solve) {
+                     hipStream_t s, IcpDevState *st, bool have_prev, const IcpTail &tail) {
   const unsigned blocks = icp_step_blocks(n);
   const int levels = nn1_per_lane() ? lane_nearest_levels(t->M) : 0;
-  {
-    TimingScope ts(PCLMI_TIMER_ICP_STEP, s);
-    if (levels > 0)
-      hipLaunchKernelGGL((icp_step_kernel<true>), dim3(blocks), dim3(64 * ICP_WPB),
-                         (size_t)ICP_WPB * levels * 64 * sizeof(float), s, t->view(), d_pts, (int)n, apply ? 1 : 0, T,
-                         (float)thr2, thr2, d_nn, d_nn_slot, d_dist, origin[0], origin[1], origin[2], d_partials,
-                         (const IcpDevState *)st, levels, have_prev ? 1 : 0);
-    else
-      hipLaunchKernelGGL((icp_step_kernel<false>), dim3(blocks), dim3(64 * ICP_WPB), 0, s, t->view(), d_pts, (int)n,
-                         apply ? 1 : 0, T, (float)thr2, thr2, d_nn, d_nn_slot, d_dist, origin[0], origin[1], origin[2],
-                         d_partials, (const IcpDevState *)st, 0, 0);
-  }
-  // the step kernel writes its partials column-major: row stride 1, column stride = blocks
-  if (fuse_solve && st)
-    hipLaunchKernelGGL(reduce_solve_kernel, dim3(NS), dim3(256), 0, s, d_partials, (int)blocks, (size_t)1, (size_t)blocks,
-                       d_sums, st);
+  TimingScope ts(PCLMI_TIMER_ICP_STEP, s);
+  if (levels > 0)
+    hipLaunchKernelGGL((icp_step_kernel<true>), dim3(blocks), dim3(64 * ICP_WPB),
+                       (size_t)ICP_WPB * levels * 64 * sizeof(float), s, t->view(), d_pts, (int)n, apply ? 1 : 0, T,
+                       (float)thr2, thr2, d_nn, d_nn_slot, d_dist, origin[0], origin[1], origin[2], d_partials,
+                       (const IcpDevState *)st, levels, have_prev ? 1 : 0, tail);
   else
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(NS), dim3(256), 0, s, d_partials, (int)blocks, (size_t)1,
-                       (size_t)blocks, d_sums, st);
+    hipLaunchKernelGGL((icp_step_kernel<false>), dim3(blocks), dim3(64 * ICP_WPB), 0, s, t->view(), d_pts, (int)n,
+                       apply ? 1 : 0, T, (float)thr2, thr2, d_nn, d_nn_slot, d_dist, origin[0], origin[1], origin[2],
+                       d_partials, (const IcpDevState *)st, 0, 0, tail);
 }
 
 unsigned pair_reduce_blocks(size_t n) {
@@ -574,7 +632,7 @@ void launch_pair_reduce(const float4 *src, const int *sidx, const float4 *tgt, c
   hipLaunchKernelGGL(pair_reduce_kernel, dim3(blocks), dim3(64 * PR_WPB), 0, s, src, sidx, tgt, tidx, flags, (int)n,
                      origin[0], origin[1], origin[2], d_partials);
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(NS), dim3(256), 0, s, d_partials, (int)blocks, (size_t)NS, (size_t)1,
-                     d_sums, (IcpDevState *)nullptr);
+                     d_sums);
 }
 
 void launch_moment_reduce(const float4 *src, const int *sidx, size_t n, double *d_partials, double *d_sums,
@@ -582,7 +640,7 @@ void launch_moment_reduce(const float4 *src, const int *sidx, size_t n, double *
   const unsigned blocks = pair_reduce_blocks(n);
   hipLaunchKernelGGL(moment_reduce_kernel, dim3(blocks), dim3(64 * PR_WPB), 0, s, src, sidx, (int)n, d_partials);
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(NS), dim3(256), 0, s, d_partials, (int)blocks, (size_t)NS, (size_t)1,
-                     d_sums, (IcpDevState *)nullptr);
+                     d_sums);
 }
 
 void launch_count_within(const float4 *src, const int *sidx, const float4 *tgt, const int *tidx, size_t n,

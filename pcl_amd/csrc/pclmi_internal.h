@@ -10,6 +10,7 @@
 #include <mutex>
 #include <vector>
 
+#include "comm_dev.hpp"
 #include "pclmi.h"
 
 namespace pclmi {
@@ -213,8 +214,22 @@ struct IcpDevState {
   int max_iterations, min_correspondences;
   double fit, tdelta;
   double transformation_epsilon, euclidean_fitness_epsilon;
-  unsigned int ticket;  // blocks of reduce_solve_kernel that have published their sum (0 between launches)
+  unsigned int ticket;  // unused (the arrival tickets of the step kernel's tail live in IcpTail)
 };
+// What the workgroup that finishes a step's reduction goes on to do (icp_kernels.hip icp_step_tail): group sums,
+// the launch's sums, the exchange with the other ranks (comm.world > 1), the solve (solve != 0, needs st).
+struct IcpTail {
+  double *gpart = nullptr;          // [PCLMI_ICP_NSUMS][ngroups] group sums
+  unsigned int *gticket = nullptr;  // [ngroups] arrival tickets, zero between launches
+  unsigned int *ticket = nullptr;   // groups finished, zero between launches
+  double *sums_out = nullptr;       // [PCLMI_ICP_NSUMS] the launch's (all-reduced) sums
+  IcpDevState *st = nullptr;
+  int solve = 0;
+  int ngroups = 1;
+  CommView comm;
+};
+CommView comm_view(const pclmi_comm *c);
+int comm_device(const pclmi_comm *c);
 void launch_transform(float4 *d_pts, size_t n, const Xf &T, hipStream_t s);
 void launch_transform_pending(float4 *d_pts, size_t n, IcpDevState *st, hipStream_t s);  // applies st->T iff st->apply
 void launch_icp_solve(const double *d_sums, IcpDevState *st, hipStream_t s);
@@ -222,11 +237,12 @@ void launch_pack(const float *d_in, size_t stride_f, const int *d_rows, size_t n
 void launch_permute(const float4 *in, const int *order, size_t n, float4 *out, hipStream_t s);
 void launch_unpermute(const float4 *in, const int *order, size_t n, float4 *out, hipStream_t s);
 unsigned icp_step_blocks(size_t n);
-// st (nullable): take the pending transform from the device-side state instead of apply / T
+unsigned icp_step_groups(size_t n);
+// st (nullable): take the pending transform from the device-side state instead of apply / T.  ONE launch: the
+// workgroup that arrives last carries out `tail` (sums, exchange, solve).
 void launch_icp_step(const pclmi_tree *t, float4 *d_pts, size_t n, bool apply, const Xf &T, double thr2,
                      int *d_nn, int *d_nn_slot, float *d_dist, const double origin[3], double *d_partials,
-                     double *d_sums, hipStream_t s, IcpDevState *st = nullptr, bool have_prev = false,
-                     bool fuse_solve = false);  // fuse_solve (needs st): the solve runs in the reduction's launch
+                     hipStream_t s, IcpDevState *st, bool have_prev, const IcpTail &tail);
 // development switch (environment PCLMI_NN1=union): 1-NN searches use the wave-uniform traversal instead of
 // the per-lane one
 bool nn1_per_lane();
