@@ -413,6 +413,17 @@ int pclmi_icp_run_dev(pclmi_icp_ctx *c, double max_correspondence_distance, int 
   return PCLMI_OK;
 }
 
+// development aid (not in pclmi.h): device wall-clock ticks (100 MHz) of the context's last step launch
+int pclmi_debug_icp_ticks(pclmi_icp_ctx *c, unsigned long long out[4]) {
+  PCLMI_CHECK(c && out, PCLMI_ERR_INVALID, "NULL argument");
+  hipStream_t s = c->user_stream ? c->user_stream : c->stream;
+  IcpDevState h;
+  PCLMI_HIP(hipMemcpyAsync(&h, c->state.p, sizeof(h), hipMemcpyDeviceToHost, s));
+  PCLMI_HIP(hipStreamSynchronize(s));
+  for (int i = 0; i < 4; ++i) out[i] = h.ticks[i];
+  return PCLMI_OK;
+}
+
 int pclmi_icp_set_comm(pclmi_icp_ctx *c, pclmi_comm *comm) {
   PCLMI_CHECK(c, PCLMI_ERR_INVALID, "NULL argument");
   PCLMI_CHECK(!comm || comm_device(comm) == c->tree->device, PCLMI_ERR_INVALID,

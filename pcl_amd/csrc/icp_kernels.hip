@@ -132,25 +132,48 @@ constexpr int ICP_WPB = 4;
 
 // One lane turns the (all-reduced) sums into the next transform and evaluates the convergence criteria
 // (icp.hpp:103-108,171-196): the device-side twin of the loop body of pclmi_icp_align.
-__device__ __forceinline__ void icp_solve_body(const double *__restrict__ sums, IcpDevState *__restrict__ st) {
+// What the solve reads of the device state, fetched by 40 lanes at once (in flight during the reduction / exchange)
+// instead of by the solving lane one dependent global load after the other - the solve sits on the critical path of
+// every iteration.  It is read only after the rotation has been computed, so none of it is live (and spilled, under
+// the step kernel's 64-VGPR budget) across that computation.
+struct SolveIn {
+  float T[16], F[16];
+  int min_corr, iterations, max_iter, pad;
+  double teps, feps;
+};
+__device__ __forceinline__ void fetch_solve_in(const IcpDevState *__restrict__ st, SolveIn *in, int lane) {
+  if (lane < 16) in->T[lane] = st->T[lane];
+  else if (lane < 32) in->F[lane - 16] = st->final_T[lane - 16];
+  else if (lane == 32) in->min_corr = st->min_correspondences;
+  else if (lane == 33) in->iterations = st->iterations;
+  else if (lane == 34) in->max_iter = st->max_iterations;
+  else if (lane == 35) in->teps = st->transformation_epsilon;
+  else if (lane == 36) in->feps = st->euclidean_fitness_epsilon;
+}
+
+// One lane turns the (all-reduced) sums into the next transform and evaluates the convergence criteria
+// (icp.hpp:103-108,171-196): the device-side twin of the loop body of pclmi_icp_align.
+__device__ __forceinline__ void icp_solve_body(const double *__restrict__ sums, IcpDevState *__restrict__ st,
+                                               double *work /* 42 doubles of LDS, rigid_solve.hpp svd3 */,
+                                               const SolveIn *in) {
   const double *h = sums;
   const long long cnt = llround(h[0]);
   st->last_pairs = (int)cnt;
-  if (cnt < (long long)st->min_correspondences) {  // icp.hpp:103-108
+  if (cnt < (long long)in->min_corr) {  // icp.hpp:103-108
     st->status = PCLMI_ERR_NOT_ENOUGH;
     st->done = 1;
     return;
   }
   float Tprev[16], T[16], F[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    Tprev[i] = st->T[i];
-    F[i] = st->final_T[i];
-  }
-  if (!rs::solve_from_sums(h, T)) {
+  if (!rs::solve_from_sums(h, T, work)) {
     st->status = PCLMI_ERR_NOT_ENOUGH;
     st->done = 1;
     return;
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    Tprev[i] = in->T[i];
+    F[i] = in->F[i];
   }
   rs::mat4_mul(T, F, F);  // icp.hpp:177
 #pragma unroll
@@ -159,15 +182,14 @@ __device__ __forceinline__ void icp_solve_body(const double *__restrict__ sums, 
     st->final_T[i] = F[i];
   }
   st->apply = 1;  // icp.hpp:174, carried out by the next step (or at the end)
-  const int it = st->iterations + 1;
+  const int it = in->iterations + 1;
   st->iterations = it;
   const double tdelta = (double)rs::transform_delta(T, Tprev);
   const double n_points = h[18] > 0 ? h[18] : 1.0;
   const double fit = h[17] / n_points;  // registration.hpp:60-68
   st->tdelta = tdelta;
   st->fit = fit;
-  if (it >= st->max_iterations || tdelta < st->transformation_epsilon ||
-      fabs(fit) <= st->euclidean_fitness_epsilon) {  // icp.hpp:193-196
+  if (it >= in->max_iter || tdelta < in->teps || fabs(fit) <= in->feps) {  // icp.hpp:193-196
     st->converged = 1;
     st->done = 1;
   }
@@ -212,6 +234,8 @@ __device__ __forceinline__ double tail_column_sum(const double *col_base, int cn
 __device__ __forceinline__ void icp_step_tail(const IcpTail &tail, double *__restrict__ partials, double (*lds)[NS]) {
   __shared__ int s_last;
   __shared__ double fin[NS];
+  __shared__ double svd_work[42];
+  __shared__ SolveIn sin;
   const int tid = threadIdx.x, lane = tid & 63;
   const int nblk = gridDim.x;
   if (tid < NS) {
@@ -246,12 +270,14 @@ __device__ __forceinline__ void icp_step_tail(const IcpTail &tail, double *__res
   }
   __syncthreads();
   if (!s_last) return;
+  const unsigned long long tk1 = (unsigned long long)wall_clock64();
   {
     const double s = tail_column_sum(tail.gpart + (size_t)(colth ? col : 0) * tail.ngroups, tail.ngroups, r, colth);
     if (colth && r == 0) fin[col] = s;
   }
   __syncthreads();
   if (tid >= 64) return;  // the first wave goes on alone
+  if (tail.st && tail.solve) fetch_solve_in(tail.st, &sin, lane);  // in flight during the exchange
   double v = lane < NS ? fin[lane] : 0.0;
   bool ok = true;
   if (tail.comm.world > 1) {
@@ -267,13 +293,16 @@ __device__ __forceinline__ void icp_step_tail(const IcpTail &tail, double *__res
     __hip_atomic_store((g_u32p)tail.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     IcpDevState *st = tail.st;
     if (st) {
+      st->ticks[1] = tk1;
+      st->ticks[2] = (unsigned long long)wall_clock64();
       st->apply = 0;  // this launch has consumed the pending transform
       if (!ok) {
         st->status = PCLMI_ERR_COMM;
         st->done = 1;
       } else if (tail.solve) {
-        icp_solve_body(fin, st);
+        icp_solve_body(fin, st, svd_work, &sin);
       }
+      st->ticks[3] = (unsigned long long)wall_clock64();
     }
   }
 }
@@ -298,6 +327,7 @@ __global__ __launch_bounds__(64 * ICP_WPB) __attribute__((amdgpu_waves_per_eu(8,
 #pragma unroll
     for (int j = 0; j < 12; ++j) T.m[j] = st->T[j];
   }
+  if (tail.st && blockIdx.x == 0 && threadIdx.x == 0) tail.st->ticks[0] = (unsigned long long)wall_clock64();
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
   const int per = (gridDim.x + 7) >> 3;
@@ -401,8 +431,13 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double *__re
 }
 
 __global__ __launch_bounds__(64) void icp_solve_kernel(const double *__restrict__ sums, IcpDevState *__restrict__ st) {
-  if (threadIdx.x != 0 || st->done) return;
-  icp_solve_body(sums, st);
+  __shared__ double work[42];
+  __shared__ SolveIn in;
+  if (st->done) return;  // uniform
+  fetch_solve_in(st, &in, threadIdx.x);
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  icp_solve_body(sums, st, work, &in);
 }
 
 __global__ void transform_pending_kernel(float4 *__restrict__ pts, int n, const IcpDevState *__restrict__ st) {

@@ -215,6 +215,9 @@ struct IcpDevState {
   double fit, tdelta;
   double transformation_epsilon, euclidean_fitness_epsilon;
   unsigned int ticket;  // unused (the arrival tickets of the step kernel's tail live in IcpTail)
+  // wall_clock64() (100 MHz) of the last step launch: [0] workgroup 0 started, [1] last workgroup arrived,
+  // [2] sums ready (after the exchange), [3] solve done.  Development aid (pclmi_debug_icp_ticks).
+  unsigned long long ticks[4];
 };
 // What the workgroup that finishes a step's reduction goes on to do (icp_kernels.hip icp_step_tail): group sums,
 // the launch's sums, the exchange with the other ranks (comm.world > 1), the solve (solve != 0, needs st).

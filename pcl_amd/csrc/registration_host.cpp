@@ -17,10 +17,14 @@
 
 namespace pclmi {
 
-void svd3_f64(const double A[9], double U[9], double S[3], double V[9]) { rs::svd3(A, U, S, V); }
+void svd3_f64(const double A[9], double U[9], double S[3], double V[9]) {
+  double work[21];
+  rs::svd3(A, U, S, V, work);
+}
 
 int solve_rigid_from_sums(const double sums[PCLMI_ICP_NSUMS], float T[16]) {
-  if (!rs::solve_from_sums(sums, T)) {
+  double work[42];
+  if (!rs::solve_from_sums(sums, T, work)) {
     set_error("pclmi_icp_solve: no correspondences (n = %g)", sums[0]);
     return PCLMI_ERR_NOT_ENOUGH;
   }

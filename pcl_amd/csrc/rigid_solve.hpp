@@ -22,7 +22,7 @@ namespace rs {
 // One rotation of the one-sided Jacobi SVD on columns P, Q (compile-time indices: everything stays in
 // registers on the GPU - a run-time index would put the matrices into scratch memory).
 template <int P, int Q>
-PCLMI_HD bool jacobi_rotate(double (&a)[9], double (&v)[9]) {
+PCLMI_HD bool jacobi_rotate(double *a, double *v) {
   double alpha = 0, beta = 0, gamma = 0;
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
@@ -51,7 +51,7 @@ PCLMI_HD bool jacobi_rotate(double (&a)[9], double (&v)[9]) {
 
 // exchange columns I and J of (s, a, v) when s[J] > s[I]
 template <int I, int J>
-PCLMI_HD void order_columns(double (&s)[3], double (&a)[9], double (&v)[9]) {
+PCLMI_HD void order_columns(double *s, double *a, double *v) {
   if (s[J] > s[I]) {
     double t = s[I];
     s[I] = s[J];
@@ -70,17 +70,23 @@ PCLMI_HD void order_columns(double (&s)[3], double (&a)[9], double (&v)[9]) {
 
 // one-sided Jacobi SVD of a 3x3, singular values descending (as Eigen::JacobiSVD orders them, so
 // that "column 2" of the determinant fix is the smallest singular direction).  A = U diag(S) V'.
-PCLMI_HD void svd3(const double A[9], double U[9], double S[3], double V[9]) {
-  double a[9], v[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+// work: 21 doubles of scratch for the rotated matrix, V and the singular values.  On the GPU the caller passes LDS
+// (the one lane that solves runs under the step kernel's 64-VGPR budget: ~40 live fp64 values in registers would
+// spill to scratch memory on the iteration's critical path; as memory operands they cost LDS latency on this rare
+// path only).  Same arithmetic wherever the arrays live.
+PCLMI_HD void svd3(const double A[9], double *U, double *S, double *V, double *work) {
+  double *a = work, *v = work + 9, *s = work + 18;
 #pragma unroll
-  for (int i = 0; i < 9; ++i) a[i] = A[i];
+  for (int i = 0; i < 9; ++i) {
+    a[i] = A[i];
+    v[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  }
   for (int sweep = 0; sweep < 30; ++sweep) {
     bool rotated = jacobi_rotate<0, 1>(a, v);
     rotated |= jacobi_rotate<0, 2>(a, v);
     rotated |= jacobi_rotate<1, 2>(a, v);
     if (!rotated) break;
   }
-  double s[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) s[c] = sqrt(a[c] * a[c] + a[3 + c] * a[3 + c] + a[6 + c] * a[6 + c]);
   order_columns<0, 1>(s, a, v);
@@ -126,8 +132,91 @@ PCLMI_HD double det3(const double M[9]) {
          M[2] * (M[3] * M[7] - M[4] * M[6]);
 }
 
+// R = V U' of H = U S V' WITHOUT the SVD, for the common case det(H) > 0 and H not close to singular: V U' is
+// then the orthogonal polar factor of H', which the scaled Newton iteration X <- (g X + X^-T / g) / 2 (Higham,
+// "Computing the polar decomposition - with applications", 1986) reaches in 5-7 steps of one 3x3 cofactor inverse
+// each - about 2 us of dependent fp64 latency for one GPU lane against ~10 us for the Jacobi sweeps, and the solve
+// sits on the critical path of every ICP iteration.  Backward stable; both give R to a few fp64 ulps of each other,
+// far inside the fp32 rounding of T.  Returns false (caller takes the SVD path, which also handles the reflection
+// fix of transformation_estimation_svd.hpp:156-160 and rank-deficient H) when the normalised determinant is not
+// safely positive.  Only IEEE +,-,*,/,sqrt: same bits on host and device.
+PCLMI_HD bool polar_rotation(const double H[9], double R[9]) {
+  double f2 = 0.0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) f2 += H[i] * H[i];
+  if (!(f2 > 0.0)) return false;
+  const double inv_f = 1.0 / sqrt(f2);
+  double X[9];  // X0 = H' / ||H||_F
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) X[r * 3 + c] = H[c * 3 + r] * inv_f;
+  bool scaled = true;
+  for (int it = 0; it < 40; ++it) {
+    double C[9];  // cofactors: X^-T = C / det
+    C[0] = X[4] * X[8] - X[5] * X[7];
+    C[1] = X[5] * X[6] - X[3] * X[8];
+    C[2] = X[3] * X[7] - X[4] * X[6];
+    C[3] = X[2] * X[7] - X[1] * X[8];
+    C[4] = X[0] * X[8] - X[2] * X[6];
+    C[5] = X[1] * X[6] - X[0] * X[7];
+    C[6] = X[1] * X[5] - X[2] * X[4];
+    C[7] = X[2] * X[3] - X[0] * X[5];
+    C[8] = X[0] * X[4] - X[1] * X[3];
+    const double det = X[0] * C[0] + X[1] * C[1] + X[2] * C[2];
+    if (it == 0 && !(det > 1e-9)) return false;  // singular values s1 s2 s3 / ||H||^3: reflection or near-singular
+    if (!(det > 0.0)) return false;
+    double a = 0.5, b = 0.5 / det;  // X <- a X + b C
+    if (scaled) {  // g = sqrt(||X^-T||_F / ||X||_F): brings the singular values to 1 from both sides
+      double nx = 0.0, nc = 0.0;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        nx += X[i] * X[i];
+        nc += C[i] * C[i];
+      }
+      const double g2 = sqrt(nc / nx) / det;  // g^2
+      const double g = sqrt(g2);
+      a = 0.5 * g;
+      b = 0.5 / (g * det);
+    }
+    double d2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const double xn = a * X[i] + b * C[i];
+      const double d = xn - X[i];
+      d2 += d * d;
+      X[i] = xn;
+    }
+    if (d2 < 1e-4) scaled = false;  // close to orthogonal: the plain iteration converges quadratically from here
+    if (d2 < 1e-20) break;          // ||step|| < 1e-10: what is left after this step is ~1e-20, below fp64 resolution
+  }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) R[i] = X[i];
+  return true;
+}
+
+// R = V U' through the SVD, with the reflection fix of transformation_estimation_svd.hpp:156-160.
+// work: 42 doubles (see svd3).
+PCLMI_HD void svd_rotation(const double H[9], double R[9], double *work) {
+  double *U = work + 21, *S = work + 30, *V = work + 33;
+  svd3(H, U, S, V, work);
+  if (det3(U) * det3(V) < 0) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) V[r * 3 + 2] = -V[r * 3 + 2];
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      double s = 0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) s += V[r * 3 + k] * U[c * 3 + k];  // V * U'
+      R[r * 3 + c] = s;
+    }
+}
+
 // sums layout: pclmi.h (PCLMI_ICP_NSUMS).  Returns false (T = identity) when there is no pair.
-PCLMI_HD bool solve_from_sums(const double *sums, float T[16]) {
+PCLMI_HD bool solve_from_sums(const double *sums, float T[16], double *work /* 42 doubles, see svd3 */) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.f : 0.f;
   const double n = sums[0];
@@ -148,22 +237,8 @@ PCLMI_HD bool solve_from_sums(const double *sums, float T[16]) {
   for (int r = 0; r < 3; ++r)
 #pragma unroll
     for (int c = 0; c < 3; ++c) H[r * 3 + c] = sums[7 + r * 3 + c] - n * ms[r] * mt[c];
-  double U[9], S[3], V[9];
-  svd3(H, U, S, V);
-  if (det3(U) * det3(V) < 0) {  // transformation_estimation_svd.hpp:156-160
-#pragma unroll
-    for (int r = 0; r < 3; ++r) V[r * 3 + 2] = -V[r * 3 + 2];
-  }
   double R[9];
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      double s = 0;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) s += V[r * 3 + k] * U[c * 3 + k];  // V * U'
-      R[r * 3 + c] = s;
-    }
+  if (!polar_rotation(H, R)) svd_rotation(H, R, work);
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     double rc = 0;

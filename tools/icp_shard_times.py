@@ -1,6 +1,9 @@
-"""Per-rank compute side of the sharded ICP loop on ONE GPU (development helper): for world sizes 1, 2, 4, 8 the first
-shard of bench.py's configs[3] source runs the device-resident loop (step + reduce + solve, no all-reduce) against the
-full 1M-point target.  Gives the compute-only ceiling of the strong scaling that the 8-GPU run adds its collective to."""
+"""Per-rank compute side of the sharded ICP loop on ONE GPU (development helper): for world sizes 1, 2, 4, 8 (and
+1024: a 977-point shard = the fixed cost of an iteration) one shard of bench.py's configs[3] source runs the
+device-resident loop (ONE kernel per iteration: step, reduction and solve; no exchange) against the full 1M-point
+target.  Gives the compute-only ceiling of the strong scaling that the 8-GPU run adds its exchange to.
+SHARD=hilbert (default): the rank's contiguous run of the Hilbert-ordered source (pclmi_icp_begin_sharded);
+SHARD=slice: a slice of the unsorted source (round 1's split)."""
 import os
 import sys
 import time
@@ -22,12 +25,13 @@ src_all = tgt[rng.permutation(n)] + rng.normal(0, 0.1, (n, 3)).astype(np.float32
 Ti = np.linalg.inv(T0)
 src_all = (src_all.astype(np.float64) @ Ti[:3, :3].T + Ti[:3, 3]).astype(np.float32)
 tree = capi.Tree(tgt)
-for world in [int(v) for v in os.environ.get("WORLDS", "1,2,4,8").split(",")]:
+hilbert = os.environ.get("SHARD", "hilbert") == "hilbert"
+for world in [int(v) for v in os.environ.get("WORLDS", "1,2,4,8,1024").split(",")]:
     per = (n + world - 1) // world
     src = src_all[:per]
     best = None
     for rep in range(3):
-        ctx = capi.IcpShard(tree, src)
+        ctx = capi.IcpShard(tree, src_all, rank=world // 2, world=world) if hilbert else capi.IcpShard(tree, src)
         torch.cuda.synchronize()
         capi.timing_enable(os.environ.get("NO_EVENTS") != "1")
         capi.timing_read(capi.TIMER_ICP_STEP, reset=True)
@@ -40,5 +44,5 @@ for world in [int(v) for v in os.environ.get("WORLDS", "1,2,4,8").split(",")]:
         ctx.end(want_aligned=False)
         if best is None or dt < best[0]:
             best = (dt, s_ms / max(s_n, 1))
-    print("world %d: %7d source points per rank: %.4f ms / iteration (step kernel %.4f ms)" %
-          (world, per, best[0] / iters * 1e3, best[1]), flush=True)
+    print("world %d (%s): %7d source points per rank: %.4f ms / iteration (step kernel incl. tail %.4f ms)" %
+          (world, "hilbert run" if hilbert else "slice", per, best[0] / iters * 1e3, best[1]), flush=True)
