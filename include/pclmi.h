@@ -77,6 +77,8 @@ int pclmi_set_device(int device);
 #define PCLMI_NTIMERS 4
 int pclmi_timing_enable(int on);
 int pclmi_timing_read(int which, double *total_ms, uint64_t *launches, int reset);
+/* Recorded event pairs not yet collected by pclmi_timing_read (a watchdog's "is the library waiting for the GPU"). */
+int pclmi_timing_pending(void);
 
 /* Index build ------------------------------------------------------------------------
  * Replaces pcl::KdTreeFLANN::setInputCloud + convertCloudToArray

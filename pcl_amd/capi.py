@@ -59,6 +59,7 @@ SIGNATURES = {
     "pclmi_set_device": (C.c_int, [C.c_int]),
     "pclmi_timing_enable": (C.c_int, [C.c_int]),
     "pclmi_timing_read": (C.c_int, [C.c_int, c_f64p, c_u64p, C.c_int]),
+    "pclmi_timing_pending": (C.c_int, []),
     "pclmi_tree_create": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int,
                                     C.POINTER(C.c_void_p)]),
     "pclmi_tree_destroy": (None, [C.c_void_p]),

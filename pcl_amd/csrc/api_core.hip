@@ -284,6 +284,55 @@ void release_ws_async(const pclmi_tree *t, Workspace *w, hipStream_t s) {
   t->pool.push_back(w);
 }
 
+int HostSlot::init() {
+  PCLMI_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  PCLMI_HIP(hipHostMalloc((void **)&h_pin, kPinBytes, hipHostMallocMapped));
+  PCLMI_HIP(hipHostGetDevicePointer((void **)&d_pin, h_pin, 0));
+  return PCLMI_OK;
+}
+
+int HostSlot::ensure(int which, size_t bytes) {
+  if (bytes <= cap[which]) return PCLMI_OK;
+  if (d[which]) (void)hipFree(d[which]);
+  d[which] = nullptr;
+  cap[which] = 0;
+  const size_t want = bytes + bytes / 8 + 4096;
+  PCLMI_HIP(hipMalloc(&d[which], want));
+  cap[which] = want;
+  return PCLMI_OK;
+}
+
+void HostSlot::release() {
+  for (int i = 0; i < 4; ++i)
+    if (d[i]) (void)hipFree(d[i]);
+  if (h_pin) (void)hipHostFree(h_pin);
+  if (s) (void)hipStreamDestroy(s);
+  *this = HostSlot();
+}
+
+HostSlot *acquire_host_slot(const pclmi_tree *t) {
+  {
+    std::lock_guard<std::mutex> g(t->mu);
+    if (!t->host_pool.empty()) {
+      HostSlot *h = t->host_pool.back();
+      t->host_pool.pop_back();
+      return h;
+    }
+  }
+  HostSlot *h = new HostSlot();
+  if (h->init() != PCLMI_OK) {
+    h->release();
+    delete h;
+    return nullptr;
+  }
+  return h;
+}
+
+void release_host_slot(const pclmi_tree *t, HostSlot *h) {
+  std::lock_guard<std::mutex> g(t->mu);
+  t->host_pool.push_back(h);
+}
+
 // argument checks + ordering pass + traversal, enqueued on s with workspace w; k_eff == 0 / nq == 0: nothing to do
 int knn_enqueue(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, size_t q_stride_bytes, int k_eff,
                        int32_t *d_idx, float *d_d2, hipStream_t s) {
@@ -331,6 +380,11 @@ int pclmi_set_device(int device) {
 int pclmi_timing_enable(int on) {
   g_timing.store(on < 0 ? 0 : on);
   return PCLMI_OK;
+}
+
+int pclmi_timing_pending(void) {
+  std::lock_guard<std::mutex> g(g_tmu);
+  return (int)g_pending.size();
 }
 
 int pclmi_timing_read(int which, double *total_ms, uint64_t *launches, int reset) {
@@ -451,6 +505,11 @@ void pclmi_tree_destroy(pclmi_tree *t) {
     delete w;
   }
   t->pool.clear();
+  for (HostSlot *h : t->host_pool) {
+    h->release();
+    delete h;
+  }
+  t->host_pool.clear();
   if (t->d_box) (void)hipFree(t->d_box);
   if (t->d_leaf) (void)hipFree(t->d_leaf);
   if (t->d_slot) (void)hipFree(t->d_slot);
@@ -499,28 +558,45 @@ int pclmi_knn(const pclmi_tree *t, const float *q, size_t nq, size_t q_stride_by
   if (nq == 0 || k_eff == 0) return PCLMI_OK;
   PCLMI_CHECK(q && idx && d2, PCLMI_ERR_INVALID, "NULL query/output pointer");
   PCLMI_HIP(hipSetDevice(t->device));
-  float *d_q = nullptr;
-  int32_t *d_idx = nullptr;
-  float *d_d2 = nullptr;
-  const size_t out_n = nq * (size_t)k_eff;
-  int rc = PCLMI_OK;
-  hipError_t e;
-  if ((e = hipMalloc(&d_q, nq * q_stride_bytes)) != hipSuccess ||
-      (e = hipMalloc(&d_idx, out_n * 4)) != hipSuccess || (e = hipMalloc(&d_d2, out_n * 4)) != hipSuccess ||
-      (e = hipMemcpy(d_q, q, nq * q_stride_bytes, hipMemcpyHostToDevice)) != hipSuccess) {
-    rc = hip_fail(e, "query upload", __FILE__, __LINE__);
-  } else {
-    rc = pclmi_knn_dev(t, d_q, nq, q_stride_bytes, k, d_idx, d_d2, nullptr);
-    if (rc == PCLMI_OK) {
-      if ((e = hipMemcpy(idx, d_idx, out_n * 4, hipMemcpyDeviceToHost)) != hipSuccess ||
-          (e = hipMemcpy(d2, d_d2, out_n * 4, hipMemcpyDeviceToHost)) != hipSuccess)
-        rc = hip_fail(e, "result download", __FILE__, __LINE__);
-    }
+  HostSlotGuard hg(t);
+  if (!hg.h) return PCLMI_ERR_HIP;
+  HostSlot *h = hg.h;
+  const size_t row = (size_t)k_eff * 4;
+  // ---- a few queries (the reference's per-point loop): the kernels read the queries from, and write the results
+  //      to, a pinned host buffer in place - one launch and one stream wait, no hipMemcpy, no allocation
+  const size_t q_bytes = nq * q_stride_bytes, r_bytes = nq * row;
+  const size_t off_i = (q_bytes + 255) & ~(size_t)255, off_d = off_i + ((r_bytes + 255) & ~(size_t)255);
+  if (off_d + r_bytes <= HostSlot::kPinBytes) {
+    std::memcpy(h->h_pin, q, q_bytes);
+    WsGuard g(t, h->s);
+    RC(knn_enqueue(t, g.w, (const float *)h->d_pin, nq, q_stride_bytes, k_eff, (int32_t *)(h->d_pin + off_i),
+                   (float *)(h->d_pin + off_d), h->s));
+    PCLMI_HIP(hipStreamSynchronize(h->s));
+    std::memcpy(idx, h->h_pin + off_i, r_bytes);
+    std::memcpy(d2, h->h_pin + off_d, r_bytes);
+    return PCLMI_OK;
   }
-  if (d_q) (void)hipFree(d_q);
-  if (d_idx) (void)hipFree(d_idx);
-  if (d_d2) (void)hipFree(d_d2);
-  return rc;
+  // ---- batches: grow-only device buffers, chunks of at most ~1 GB of queries + results (4M queries at k = 32:
+  //      the batch size of BASELINE configs[4]); the search of chunk c + 1 is queued behind the download of chunk c
+  const size_t per_q = q_stride_bytes + 2 * row;
+  size_t chunk = ((size_t)1 << 30) / per_q;
+  chunk = chunk < 65536 ? 65536 : chunk;
+  chunk = chunk > nq ? nq : chunk;
+  RC(h->ensure(0, chunk * q_stride_bytes));
+  RC(h->ensure(1, chunk * row));
+  RC(h->ensure(2, chunk * row));
+  WsGuard g(t, h->s);
+  for (size_t a = 0; a < nq; a += chunk) {
+    const size_t m = nq - a < chunk ? nq - a : chunk;
+    PCLMI_HIP(hipMemcpyAsync(h->d[0], (const char *)q + a * q_stride_bytes, m * q_stride_bytes, hipMemcpyHostToDevice,
+                             h->s));
+    RC(knn_enqueue(t, g.w, (const float *)h->d[0], m, q_stride_bytes, k_eff, (int32_t *)h->d[1], (float *)h->d[2],
+                   h->s));
+    PCLMI_HIP(hipMemcpyAsync(idx + a * (size_t)k_eff, h->d[1], m * row, hipMemcpyDeviceToHost, h->s));
+    PCLMI_HIP(hipMemcpyAsync(d2 + a * (size_t)k_eff, h->d[2], m * row, hipMemcpyDeviceToHost, h->s));
+  }
+  PCLMI_HIP(hipStreamSynchronize(h->s));
+  return PCLMI_OK;
 }
 
 void pclmi_free(void *p) { free(p); }

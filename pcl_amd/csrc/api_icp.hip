@@ -130,16 +130,19 @@ static int nn1_of(const pclmi_tree *tree, const float *pts, size_t n_rows, size_
   idx.assign(n, -1);
   d2.assign(n, 0.f);
   if (n == 0 || tree->n == 0) return PCLMI_OK;
-  DevBuf<float4> d;
-  RC(upload_packed(pts, n_rows, stride_bytes, rows, n_sel, d, nullptr));
-  DevBuf<int> di;
-  DevBuf<float> dd;
-  RC(di.alloc(n));
-  RC(dd.alloc(n));
-  RC(pclmi_knn_dev(tree, (const float *)d.p, n, 16, 1, di.p, dd.p, nullptr));
-  PCLMI_HIP(hipMemcpy(idx.data(), di.p, n * 4, hipMemcpyDeviceToHost));
-  PCLMI_HIP(hipMemcpy(d2.data(), dd.p, n * 4, hipMemcpyDeviceToHost));
-  return PCLMI_OK;
+  if (!rows) return pclmi_knn(tree, pts, n, stride_bytes, 1, idx.data(), d2.data(), nullptr);  // pooled staging
+  // selected rows: gather on the host, then the same path
+  std::vector<float> sel(n * 3);
+  const size_t sf = stride_bytes / 4;
+  for (size_t i = 0; i < n; ++i) {
+    const size_t r = (size_t)rows[i];
+    PCLMI_CHECK(r < n_rows, PCLMI_ERR_INVALID, "index %zu out of range (%zu rows)", r, n_rows);
+    const float *p = pts + r * sf;
+    sel[i * 3 + 0] = p[0];
+    sel[i * 3 + 1] = p[1];
+    sel[i * 3 + 2] = p[2];
+  }
+  return pclmi_knn(tree, sel.data(), n, 12, 1, idx.data(), d2.data(), nullptr);
 }
 
 int pclmi_correspondences(const pclmi_tree *target, const float *src, size_t n_src, size_t stride_bytes,

@@ -90,6 +90,7 @@ struct TreeView {
 };
 
 struct Workspace; // per-call scratch (Morton keys, permutations, sort temp), pooled per tree
+struct HostSlot;  // per-call staging of the host-pointer entry points, pooled per tree
 
 }  // namespace pclmi
 
@@ -107,6 +108,7 @@ struct pclmi_tree {
   // workspace pool (const search calls are re-entrant: each takes a workspace)
   mutable std::mutex mu;
   mutable std::vector<pclmi::Workspace *> pool;
+  mutable std::vector<pclmi::HostSlot *> host_pool;
 
   pclmi::TreeView view() const { return pclmi::TreeView{d_box, d_leaf, d_cloud, d_slot, M, (int)n}; }
 };
@@ -143,6 +145,32 @@ struct Workspace {
 
 // s: the stream the caller is going to use the workspace on (a workspace released with work still in flight on
 // another stream is ordered behind that work with hipStreamWaitEvent)
+// Staging of the host-pointer entry points (pclmi_knn, pclmi_radius, pclmi_correspondences ...): a stream of its
+// own, grow-only device buffers, and a small host buffer that the GPU reads and writes in place (pinned, mapped), so
+// that the steady state performs no hipMalloc / hipFree and a call of a few queries - the reference's normal usage is
+// one call per point (search/include/pcl/search/search.h:252-253) - no hipMemcpy either.
+struct HostSlot {
+  hipStream_t s = nullptr;
+  void *d[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t cap[4] = {0, 0, 0, 0};
+  unsigned char *h_pin = nullptr;  // host address of the mapped buffer
+  unsigned char *d_pin = nullptr;  // its device address
+  static constexpr size_t kPinBytes = (size_t)1 << 20;
+  int init();
+  int ensure(int which, size_t bytes);
+  void release();
+};
+HostSlot *acquire_host_slot(const pclmi_tree *t);  // nullptr (error text set) on failure
+void release_host_slot(const pclmi_tree *t, HostSlot *h);
+struct HostSlotGuard {
+  const pclmi_tree *t;
+  HostSlot *h;
+  explicit HostSlotGuard(const pclmi_tree *tt) : t(tt), h(acquire_host_slot(tt)) {}
+  ~HostSlotGuard() {
+    if (h) release_host_slot(t, h);
+  }
+};
+
 Workspace *acquire_ws(const pclmi_tree *t, hipStream_t s);
 void release_ws(const pclmi_tree *t, Workspace *w);                       // the caller has synchronised its stream
 void release_ws_async(const pclmi_tree *t, Workspace *w, hipStream_t s);  // work using w is still queued on s

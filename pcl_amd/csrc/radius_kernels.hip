@@ -17,6 +17,8 @@
 //                     idx / d2 arrays (and truncation to max_nn).
 // Queries are visited in Morton-cell order like the kNN path; segments are laid out in the caller's
 // query order.
+#include <cstring>
+
 #include <hipcub/hipcub.hpp>
 
 #include "pclmi_internal.h"
@@ -701,20 +703,28 @@ int pclmi_radius(const pclmi_tree *t, const float *q, size_t nq, size_t q_stride
   *idx = nullptr;
   *d2 = nullptr;
   PCLMI_HIP(hipSetDevice(t->device));
-  float *d_q = nullptr;
-  uint64_t *d_off = nullptr;
+  // queries and offsets are staged in the tree's pooled host-path buffers (no hipMalloc / hipFree in the steady
+  // state); a few queries are read by the kernels straight from the slot's pinned host buffer
+  HostSlotGuard hg(t);
+  if (!hg.h) return PCLMI_ERR_HIP;
+  HostSlot *h = hg.h;
   int32_t *d_idx = nullptr;
   float *d_d2 = nullptr;
   uint64_t total = 0;
-  int rc = PCLMI_OK;
-  hipError_t e;
-  if ((e = hipMalloc(&d_q, (nq ? nq : 1) * q_stride_bytes)) != hipSuccess ||
-      (e = hipMalloc(&d_off, (nq + 1) * sizeof(uint64_t))) != hipSuccess ||
-      (nq && (e = hipMemcpy(d_q, q, nq * q_stride_bytes, hipMemcpyHostToDevice)) != hipSuccess)) {
-    rc = hip_fail(e, "query upload", __FILE__, __LINE__);
+  const size_t q_bytes = nq * q_stride_bytes;
+  const float *d_q = nullptr;
+  if (q_bytes <= HostSlot::kPinBytes) {
+    if (nq) std::memcpy(h->h_pin, q, q_bytes);
+    d_q = (const float *)h->d_pin;
   } else {
-    rc = pclmi_radius_dev(t, d_q, nq, q_stride_bytes, radius, max_nn, sorted, d_off, &d_idx, &d_d2, &total, nullptr);
+    RC(h->ensure(0, q_bytes));
+    PCLMI_HIP(hipMemcpyAsync(h->d[0], q, q_bytes, hipMemcpyHostToDevice, h->s));
+    d_q = (const float *)h->d[0];
   }
+  RC(h->ensure(3, (nq + 1) * sizeof(uint64_t)));
+  uint64_t *d_off = (uint64_t *)h->d[3];
+  int rc = pclmi_radius_dev(t, d_q, nq, q_stride_bytes, radius, max_nn, sorted, d_off, &d_idx, &d_d2, &total, h->s);
+  hipError_t e;
   if (rc == PCLMI_OK) {
     int32_t *hi = (int32_t *)malloc((total ? total : 1) * sizeof(int32_t));
     float *hd = (float *)malloc((total ? total : 1) * sizeof(float));
@@ -723,9 +733,10 @@ int pclmi_radius(const pclmi_tree *t, const float *q, size_t nq, size_t q_stride
       free(hd);
       set_error("out of host memory for %llu radius results", (unsigned long long)total);
       rc = PCLMI_ERR_OOM;
-    } else if ((e = hipMemcpy(offsets, d_off, (nq + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost)) != hipSuccess ||
-               (total && ((e = hipMemcpy(hi, d_idx, total * sizeof(int32_t), hipMemcpyDeviceToHost)) != hipSuccess ||
-                          (e = hipMemcpy(hd, d_d2, total * sizeof(float), hipMemcpyDeviceToHost)) != hipSuccess))) {
+    } else if ((e = hipMemcpyAsync(offsets, d_off, (nq + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, h->s)) != hipSuccess ||
+               (total && ((e = hipMemcpyAsync(hi, d_idx, total * sizeof(int32_t), hipMemcpyDeviceToHost, h->s)) != hipSuccess ||
+                          (e = hipMemcpyAsync(hd, d_d2, total * sizeof(float), hipMemcpyDeviceToHost, h->s)) != hipSuccess)) ||
+               (e = hipStreamSynchronize(h->s)) != hipSuccess) {
       free(hi);
       free(hd);
       rc = hip_fail(e, "result download", __FILE__, __LINE__);
@@ -734,8 +745,6 @@ int pclmi_radius(const pclmi_tree *t, const float *q, size_t nq, size_t q_stride
       *d2 = hd;
     }
   }
-  if (d_q) (void)hipFree(d_q);
-  if (d_off) (void)hipFree(d_off);
   pclmi_free_dev(d_idx);  // result buffers belong to the library's cache (never hipFree them directly)
   pclmi_free_dev(d_d2);
   return rc;

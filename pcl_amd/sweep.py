@@ -1,0 +1,69 @@
+"""Streamed k-NN sweep: BASELINE configs[4] (100M queries, k = 32, against a 10M-point target) as a workload.
+
+The batched form of the reference's per-point loop (search/include/pcl/search/search.h:244-262) at a size where the
+queries do not arrive in one piece: a rank's share of the queries (12.5M of the 100M on 8 GPUs) is uploaded in
+batches (4M by default) on a copy stream while the previous batch is searched on the compute stream
+(pclmi_knn_dev_async: enqueue-only, the workspace changes hands in stream order); the neighbour lists stay in HBM
+(12.5M x 32 x 8 B = 3.2 GB).  Queries shard over ranks with no collective.  torch is plumbing: pinned host memory,
+device buffers, streams and events.
+"""
+import numpy as np
+
+
+def rank_slice(n_total, rank, world):
+    """Contiguous share of `n_total` queries of rank `rank` (the last rank takes the remainder)."""
+    per = (n_total + world - 1) // world
+    lo = min(n_total, rank * per)
+    return lo, min(n_total, lo + per)
+
+
+def knn_sweep(tree, queries, k, batch=4_000_000, device=None, out=None, timings=None):
+    """queries: (n, 3 | 4) float32 host array (numpy, or a pinned torch tensor).  Returns (idx, d2) CUDA tensors
+    [n, k_eff] resident in HBM.  timings (dict, optional) receives the wall time of the pipeline in seconds."""
+    import time
+
+    import torch
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    if isinstance(queries, np.ndarray):
+        q = torch.from_numpy(np.ascontiguousarray(queries, np.float32))
+    else:
+        q = queries
+    assert q.dim() == 2 and q.shape[1] in (3, 4) and q.dtype == torch.float32
+    if not q.is_pinned():
+        q = q.pin_memory()  # asynchronous uploads need page-locked memory
+    n, w = q.shape
+    k_eff = min(k, len(tree))
+    if out is None:
+        idx = torch.empty((n, k_eff), dtype=torch.int32, device=dev)
+        d2 = torch.empty((n, k_eff), dtype=torch.float32, device=dev)
+    else:
+        idx, d2 = out
+        assert idx.shape == (n, k_eff) and d2.shape == (n, k_eff)
+    if n == 0 or k_eff == 0:
+        return idx, d2
+    batch = max(1, min(batch, n))
+    stage = [torch.empty((batch, w), dtype=torch.float32, device=dev) for _ in range(2)]
+    up, run = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    uploaded = [torch.cuda.Event() for _ in range(2)]
+    searched = [torch.cuda.Event() for _ in range(2)]
+    cur = torch.cuda.current_stream(dev)
+    up.wait_stream(cur)
+    run.wait_stream(cur)
+    t0 = time.perf_counter()
+    for b, a in enumerate(range(0, n, batch)):
+        m = min(batch, n - a)
+        s = b % 2
+        with torch.cuda.stream(up):
+            if b >= 2:
+                up.wait_event(searched[s])  # the staging buffer is free once its previous batch has been searched
+            stage[s][:m].copy_(q[a:a + m], non_blocking=True)
+            uploaded[s].record(up)
+        run.wait_event(uploaded[s])
+        tree.knn_dev_async(stage[s].data_ptr(), m, w * 4, k, idx[a:a + m].data_ptr(), d2[a:a + m].data_ptr(),
+                           run.cuda_stream)
+        searched[s].record(run)
+    run.synchronize()
+    if timings is not None:
+        timings["seconds"] = time.perf_counter() - t0
+    cur.wait_stream(run)
+    return idx, d2
