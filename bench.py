@@ -9,25 +9,37 @@ N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-
 Workload (BASELINE.json configs[1], SURVEY 8d "C2"): synthetic 1 000 000-point target uniform in
 [0,1024)^3 (seed 20260101), replicated on every GPU; 1 000 000 queries per GPU from the same cube
 (seed 20260102 + rank), k = 16.  One step = one pclmi_knn_dev call over the rank's 1M queries:
-query ordering (Morton-cell counting sort) + the traversal kernel, inputs and outputs resident in
+query ordering (Hilbert-cell counting sort) + the traversal kernel, inputs and outputs resident in
 HBM.  Queries are sharded with no data-path collective, so scaling is "weak".
 
 The same line carries
   roofline      HIP-event time of the traversal kernel (pclmi_timing_*, events recorded on the
                 stream the kernel runs on) against the algorithmic bytes of SURVEY 8d:
                 16 B query + 8 B x k results per query + 16 B per target point = 160 MB / launch;
-  cpu_baseline  the CPU oracle's FLANN-style kd-tree (oracle/, OpenMP over queries) on the host
-                cores of this box, same inputs, rank 0 at N = 1 only;
-  icp           ICP iterations / s on BASELINE configs[3] (1M source vs 1M target, 30 iterations,
-                source sharded over the ranks, one all-reduce of 24 fp64 sums per iteration; the
-                loop is device-resident: step kernel, all-reduce and solve kernel are enqueued on
-                one stream, the host reads the result once).
+                `traffic` is NOT measured in this run: it is read from the committed rocprofv3 PMC
+                summary named in `traffic_from` (file + the commit it was taken at);
+  cpu_baseline  the CPU oracle's FLANN-style kd-tree (oracle/, OpenMP over queries, compiled on this
+                box with -O3 -march=native -ffp-contract=off) on the host cores of this box, same
+                inputs, rank 0 at N = 1 only;
+  icp           ICP iterations / s on BASELINE configs[3] (1M source vs 1M target, 30 iterations):
+                the source is Hilbert-ordered and cut into one contiguous run per rank; an iteration is
+                ONE kernel per rank whose last workgroup exchanges the 24 fp64 sums with the other
+                ranks (pclmi_comm: peer mailboxes over xGMI) and solves; the host reads the result once.
+                With N > 1 the same align is also timed with the exchange as an RCCL all-reduce between
+                the step and the solve kernels (torch.distributed), reported beside it;
+  extras        configs[4] (one GPU's 12.5M-query share of the k = 32 sweep on the 10M-point target,
+                streamed in 4M batches), configs[2] (radius search, ~32 neighbours), the PCIe-inclusive
+                host-pointer rate, single-query latency, ICP with the RANSAC rejection step on.
 torch is used for device memory, streams and torch.distributed only.
 """
 import argparse
+import ctypes as C
 import json
 import os
+import subprocess
 import sys
+import tempfile
+import threading
 import time
 
 import numpy as np
@@ -75,45 +87,70 @@ def rigid(angle_deg, axis, trans):
     return T
 
 
-def pmc_traffic(which="knn16"):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
-    (profiles/*<which>*_pmc.json, produced by tools/pmc_summary.py / tools/pmc_icp.sh; FETCH_SIZE doubled per
-    the gfx950 note of the micro-architecture guide); None when no summary is committed."""
-    import glob
-    best = None
-    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*%s*_pmc.json" % which))):
-        try:
-            d = json.load(open(p))
-            best = d.get("hbm_bytes_per_launch")
-            if best is None and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
-                best = (2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024
-        except Exception:
-            pass
-    return best
+def icp_clouds():
+    """configs[3]: surface-like 1M-point target; source = the target permuted, moved by a known rigid motion
+    (1 degree about (1,1,1) through the cloud centre + (2,-1,0.5)) and perturbed by sigma = 0.1 noise."""
+    n = 1_000_000
+    tgt = surface_cloud(n, SEED_T + 10)
+    T0 = rigid(1.0, (1, 1, 1), (2.0, -1.0, 0.5))
+    c = np.array([512.0, 512.0, 512.0])
+    T0[:3, 3] += c - T0[:3, :3] @ c
+    rng = np.random.default_rng(SEED_Q + 10)
+    src = tgt[rng.permutation(n)] + rng.normal(0, 0.1, (n, 3)).astype(np.float32)
+    Ti = np.linalg.inv(T0)
+    src = (src.astype(np.float64) @ Ti[:3, :3].T + Ti[:3, 3]).astype(np.float32)
+    return tgt, src, T0
 
 
-def pmc_valu_issue(which, kernel_ms, n_simd=1024, clock_ghz=2.4):
-    """Fraction of the launch's VALU issue slots the kernel used: SQ_INSTS_VALU of the committed PMC summary x 4
-    cycles per wave64 instruction / (SIMDs x kernel cycles at the 2.4 GHz peak engine clock).  None without a summary."""
+def pmc_summary(which):
+    """The committed rocprofv3 PMC summary of the kernel (profiles/*<which>*_pmc.json, produced by
+    tools/pmc_summary.py / tools/pmc_icp.sh) and where it comes from.  These counters are NOT collected by this run:
+    the line names the file and the commit that last touched it so that stale counters cannot pass for measured ones."""
     import glob
+    best, src = None, None
     for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*%s*_pmc.json" % which))):
         try:
-            v = json.load(open(p)).get("SQ_INSTS_VALU")
-            if v:
-                return 4.0 * v / (n_simd * kernel_ms * 1e-3 * clock_ghz * 1e9)
+            best, src = json.load(open(p)), p
         except Exception:
             pass
-    return None
+    if best is None:
+        return None, None
+    rel = os.path.relpath(src, ROOT)
+    commit = None
+    try:
+        commit = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h %cI", "--", rel], capture_output=True,
+                                text=True, timeout=10).stdout.strip() or None
+    except Exception:
+        pass
+    return best, {"file": rel, "commit": commit, "note": "committed rocprofv3 --pmc summary, not collected by this run"}
+
+
+def pmc_traffic(d):
+    if d is None:
+        return None
+    v = d.get("hbm_bytes_per_launch")
+    if v is None and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+        v = (2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024  # FETCH doubled per the guide's gfx950 note
+    return v
+
+
+def pmc_valu_issue(d, kernel_ms, n_simd=1024, clock_ghz=2.4):
+    """Fraction of the launch's VALU issue slots the kernel used: SQ_INSTS_VALU x 4 cycles per wave64 instruction /
+    (SIMDs x kernel cycles at the 2.4 GHz peak engine clock)."""
+    if d is None or not d.get("SQ_INSTS_VALU"):
+        return None
+    return 4.0 * d["SQ_INSTS_VALU"] / (n_simd * kernel_ms * 1e-3 * clock_ghz * 1e9)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--icp-iters", type=int, default=30)
     ap.add_argument("--no-icp", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -124,7 +161,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     # Rehearsal of the N > 1 path on a one-GPU box (never used by the driver): every rank on device 0,
-    # collectives over gloo instead of RCCL (RCCL refuses two ranks on one GPU).
+    # torch's collectives (barrier, max over ranks) over gloo instead of RCCL (RCCL refuses two ranks on one GPU);
+    # the ICP exchange is pclmi_comm either way (HIP IPC works between processes on one device).
     rehearsal = os.environ.get("PCLMI_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local = 0
@@ -144,11 +182,39 @@ def main():
     capi.load_library().pclmi_set_device(local)
 
     verbose = rehearsal or os.environ.get("PCLMI_BENCH_VERBOSE") == "1"
-    if verbose:  # a stuck rank says where: stack dump after PCLMI_BENCH_WATCHDOG seconds (default 150), then exit
+    tstream = torch.cuda.Stream(device=dev)
+    phase = {"name": "start"}
+    if verbose or world > 1:
+        # A stuck rank says where AND what is stuck: after PCLMI_BENCH_WATCHDOG seconds (default 240) of one phase the
+        # watchdog prints whether the bench stream has drained (hipStreamQuery: "GPU busy" vs "GPU idle, host or
+        # collective stuck"), how many of the library's event pairs are still pending, every Python stack, and exits.
         import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ.get("PCLMI_BENCH_WATCHDOG", "150")), exit=True)
+        limit = float(os.environ.get("PCLMI_BENCH_WATCHDOG", "240"))
+
+        def watchdog():
+            last, since = phase["name"], time.time()
+            while True:
+                time.sleep(1.0)
+                if phase["name"] != last:
+                    last, since = phase["name"], time.time()
+                elif phase["name"] == "done":
+                    return
+                elif time.time() - since > limit:
+                    try:
+                        drained = tstream.query()
+                    except Exception as e:  # noqa: BLE001
+                        drained = "query failed: %r" % (e,)
+                    print("[bench rank %d] WATCHDOG: phase '%s' has not finished in %.0f s; bench stream drained: %s; "
+                          "library timer event pairs pending: %d" %
+                          (rank, last, limit, drained, capi.load_library().pclmi_timing_pending()),
+                          file=sys.stderr, flush=True)
+                    faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+                    os._exit(3)
+
+        threading.Thread(target=watchdog, daemon=True).start()
 
     def log(msg):
+        phase["name"] = msg
         if verbose:
             print("[bench rank %d] %s" % (rank, msg), file=sys.stderr, flush=True)
 
@@ -161,9 +227,12 @@ def main():
     def max_over_ranks(x):
         if world == 1:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
+
+    env = dict(args=args, capi=capi, torch=torch, dist=dist, world=world, rank=rank, dev=dev, barrier=barrier,
+               max_over_ranks=max_over_ranks, log=log, rehearsal=rehearsal)
 
     # ---- kNN headline -------------------------------------------------------------------------
     log("process group up (world %d), building the target tree" % world)
@@ -176,7 +245,6 @@ def main():
     idx = torch.empty((N_QUERY, K), dtype=torch.int32, device=dev)
     d2 = torch.empty((N_QUERY, K), dtype=torch.float32, device=dev)
     # an explicit (non-null) torch stream: the library enqueues on it, torch and RCCL order against it
-    tstream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
     torch.cuda.synchronize()
@@ -195,10 +263,10 @@ def main():
     for _ in range(args.steps):
         step()
     barrier()
-    log("timed region done")
     elapsed = max_over_ranks(time.perf_counter() - t0)
+    log("timed region done")
     k_ms, k_n = capi.timing_read(capi.TIMER_KNN, reset=True)
-    # the ordering pass (counting sort by Morton cell) is timed in a short pass of its own, outside the timed region
+    # the ordering pass (counting sort by Hilbert cell) is timed in a short pass of its own, outside the timed region
     capi.timing_enable(2 << capi.TIMER_ORDER)
     capi.timing_read(capi.TIMER_ORDER, reset=True)
     for _ in range(5):
@@ -210,7 +278,7 @@ def main():
     kern_ms = k_ms / max(k_n, 1)
     algo_bytes = 16 * N_QUERY + 8 * K * N_QUERY + 16 * N_TARGET
     achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
-    traffic = pmc_traffic()
+    pmc, pmc_from = pmc_summary("knn16")
 
     # size-independent sanity of the timed outputs (full parity lives in tests/): ascending rows,
     # first neighbour recomputed from the coordinates
@@ -240,100 +308,312 @@ def main():
                    "parallelism": "target replicated, queries sharded x%d" % world,
                    "tree_build_s": round(build_s, 3)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "knn_union_ix_kernel<16,40,1>", "kernel_ms": kern_ms, "launches": int(k_n),
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(pmc), "traffic_from": pmc_from,
+                     "kernel": tree.knn_kernel_name(K, N_QUERY), "kernel_ms": kern_ms, "launches": int(k_n),
                      "algorithmic_bytes_per_launch": algo_bytes,
                      "order_ms": o_ms / max(o_n, 1),
                      # the traversal is VALU-issue-bound, not HBM-bound: the binding resource beside
-                     # the nominal HBM fraction
-                     "valu_issue_frac": pmc_valu_issue("knn16", kern_ms)},
+                     # the nominal HBM fraction (from the same committed PMC summary as `traffic`)
+                     "valu_issue_frac": pmc_valu_issue(pmc, kern_ms)},
     }
 
     # ---- ICP iterations / s (configs[3]) -------------------------------------------------------
     if not args.no_icp:
         log("kNN done: %.3e queries/s; ICP next" % value)
-        out["icp"] = bench_icp(args, capi, torch, dist, world, rank, dev, barrier, max_over_ranks, log)
+        out["icp"] = bench_icp(env)
+
+    # ---- extras: the other configurations of BASELINE.json as measured side lines ----------------
+    if not args.no_extras:
+        out["extras"] = bench_extras(env, tree, target, q_host, q, stream)
 
     # ---- CPU baseline (rank 0, N = 1 only) -----------------------------------------------------
     if world == 1 and not args.no_cpu:
+        log("CPU baseline")
         out["cpu_baseline"] = cpu_baseline(target, q_host, idx, d2)
 
+    phase["name"] = "done"
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 
 
-def bench_icp(args, capi, torch, dist, world, rank, dev, barrier, max_over_ranks, log=lambda m: None):
-    n = 1_000_000
-    tgt = surface_cloud(n, SEED_T + 10)
-    # rigid motion to recover: 1 degree about (1,1,1) through the cloud centre + (2,-1,0.5)
-    T0 = rigid(1.0, (1, 1, 1), (2.0, -1.0, 0.5))
-    c = np.array([512.0, 512.0, 512.0])
-    T0[:3, 3] += c - T0[:3, :3] @ c
-    rng = np.random.default_rng(SEED_Q + 10)
-    src_all = tgt[rng.permutation(n)] + rng.normal(0, 0.1, (n, 3)).astype(np.float32)
-    Ti = np.linalg.inv(T0)
-    src_all = (src_all.astype(np.float64) @ Ti[:3, :3].T + Ti[:3, 3]).astype(np.float32)
-    per = (n + world - 1) // world
-    src = src_all[rank * per:(rank + 1) * per]
+def bench_icp(env):
+    args, capi, torch, dist = env["args"], env["capi"], env["torch"], env["dist"]
+    world, rank, dev, barrier, max_over_ranks, log = (env[k] for k in ("world", "rank", "dev", "barrier",
+                                                                       "max_over_ranks", "log"))
+    tgt, src_all, T0 = icp_clouds()
+    n = len(src_all)
     tree = capi.Tree(tgt)
     sums = torch.zeros(capi.ICP_NSUMS, dtype=torch.float64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     thr = 25.0
     iters = args.icp_iters
+    comm = None
+    if world > 1:
+        # the exchange below the C ABI: peer mailboxes mapped through HIP IPC; the handles travel through a POSIX
+        # shared-memory object named after this job (launcher pid + rendezvous port)
+        log("pclmi_comm rendezvous")
+        name = "bench_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
+        comm = capi.Comm.from_shm(rank, world, name)
+        comm.set_timeout(float(os.environ.get("PCLMI_COMM_TIMEOUT", "20")))
 
-    def run():
-        """One align of `iters` iterations, device-resident: step kernel -> (all-reduce) -> solve kernel,
-        enqueued back to back on one stream; the host reads the state once at the end."""
-        ctx = capi.IcpShard(tree, src)  # upload + Morton ordering of the shard: setup, not an iteration
+    def make_ctx():
+        # every rank passes the whole source: it is Hilbert-ordered once and cut into contiguous runs
+        return capi.IcpShard(tree, src_all, rank=rank, world=world)
+
+    def run(mode):
+        """One align of `iters` iterations, device-resident.  mode "fused": ONE kernel per iteration per rank (step,
+        reduction, exchange through pclmi_comm, solve); mode "rccl": step kernel -> RCCL all-reduce -> solve kernel."""
+        ctx = make_ctx()  # upload + Hilbert ordering of the shard: setup, not an iteration
+        if mode == "fused" and comm is not None:
+            ctx.set_comm(comm)
         barrier()
         t0 = time.perf_counter()
-        if world == 1:
+        if mode == "fused":
             ctx.run_dev(thr, iters, stream)
         else:
             for _ in range(iters):
                 ctx.step_dev(thr, sums.data_ptr(), stream)
-                dist.all_reduce(sums)  # the ONE exchange of an iteration: 24 fp64 sums over xGMI (RCCL)
+                dist.all_reduce(sums)  # 24 fp64 sums over xGMI (RCCL), between the library's kernels
                 ctx.solve_dev(sums.data_ptr(), stream)
         rc, T_final, st = ctx.state()  # synchronises the stream
         barrier()
         dt = time.perf_counter() - t0
-        assert rc == 0 and st.iterations == iters, (rc, st.iterations)
+        shard = ctx.shard_size
         ctx.end(want_aligned=False)
-        return dt, T_final, st.last_correspondences
+        return rc, dt, T_final, st, shard
 
     log("ICP clouds and tree ready, warm-up align")
-    run()  # warm-up pass (allocations, first-touch, RCCL channel set-up)
-    log("ICP warm-up done, timed align")
-    dt, T_final, npairs = run()  # the timed align carries no instrumentation (events cost ~7 us per iteration)
-    elapsed = max_over_ranks(dt)
+    rc, _, _, _, shard = run("fused")  # warm-up pass (allocations, first touch, peer mappings)
+    exchange = "none (one GPU)" if world == 1 else "pclmi_comm: peer mailboxes, fused into the step kernel"
+    res = None
+    if rc == 0:
+        log("ICP warm-up done, timed align")
+        rc, dt, T_final, st, shard = run("fused")  # the timed align carries no instrumentation
+        if rc == 0:
+            res = (max_over_ranks(dt), T_final, st)
+    rccl = None
+    if world > 1 and not env["rehearsal"]:
+        log("ICP align with the exchange as an RCCL all-reduce")
+        run("rccl")
+        rc2, dt2, T2, st2, _ = run("rccl")
+        if rc2 == 0:
+            rccl = (max_over_ranks(dt2), T2, st2)
+    if res is None:  # the mailbox exchange timed out (reported, never silent): the RCCL line is the result
+        assert rccl is not None, "ICP align failed with status %d and there is no RCCL run to report" % rc
+        exchange = "RCCL all-reduce (pclmi_comm exchange failed with status %d)" % rc
+        res = rccl
+    elapsed, T_final, st = res
+    assert st.iterations == iters, st.iterations
     log("ICP timed align done, instrumented align")
-    capi.timing_enable(2 << capi.TIMER_ICP_STEP)  # a third align, with HIP events around every step kernel
-    capi.timing_read(capi.TIMER_ICP_STEP, reset=True)
-    run()
-    s_ms, s_n = capi.timing_read(capi.TIMER_ICP_STEP, reset=True)
-    capi.timing_enable(False)
+    # per-iteration step-kernel times (HIP events around each launch; the launch includes reduction, exchange and
+    # solve): one more align, iteration by iteration
+    per_iter = []
+    if world == 1:
+        capi.timing_enable(2 << capi.TIMER_ICP_STEP)
+        ctx = make_ctx()
+        for _ in range(iters):
+            capi.timing_read(capi.TIMER_ICP_STEP, reset=True)
+            ctx.run_dev(thr, 1, stream)
+            ctx.state()
+            ms, cnt = capi.timing_read(capi.TIMER_ICP_STEP, reset=True)
+            per_iter.append(ms / max(cnt, 1))
+        ctx.end(want_aligned=False)
+        capi.timing_enable(False)
     err = float(np.abs(T_final - T0).max())
-    step_ms = s_ms / max(s_n, 1)
-    algo = 52 * len(src) + 16 * n  # SURVEY 8d: 52 B / source point + first touch of the target
-    return {"metric": "ICP iterations/sec (1M source vs 1M target, point-to-point, RANSAC off)",
-            "value": iters / elapsed, "unit": "iterations/s", "iterations": iters, "scaling": "strong",
-            "ms_per_iteration": elapsed / iters * 1e3, "n_source_total": n, "n_source_per_gpu": len(src),
-            "last_pairs_global": npairs, "max_abs_err_vs_true_transform": err,
-            "step_kernel_ms": step_ms, "step_kernel_ms_from": "a separate align with HIP events around each step",
-            "roofline": {"bound": "hbm", "achieved": algo / (step_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": algo / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic("icp_step") if world == 1 else None,
-                         "kernel": "icp_step_kernel<true>", "algorithmic_bytes_per_launch": algo}}
+    step_ms = float(np.mean(per_iter)) if per_iter else None
+    algo = 52 * shard + 16 * n  # SURVEY 8d: 52 B / source point + first touch of the target
+    pmc, pmc_from = pmc_summary("icp_step")
+    out = {"metric": "ICP iterations/sec (1M source vs 1M target, point-to-point, RANSAC off)",
+           "value": iters / elapsed, "unit": "iterations/s", "iterations": iters, "scaling": "strong",
+           "ms_per_iteration": elapsed / iters * 1e3, "n_source_total": n, "n_source_per_gpu": shard,
+           "shards": "contiguous runs of the Hilbert-ordered source", "exchange": exchange,
+           "last_pairs_global": st.last_correspondences, "max_abs_err_vs_true_transform": err}
+    if rccl is not None:
+        out["rccl_exchange_ms_per_iteration"] = rccl[0] / iters * 1e3
+        out["rccl_vs_fused_transform_max_abs_diff"] = float(np.abs(rccl[1] - T_final).max())
+    if step_ms:
+        out.update({"step_kernel_ms": step_ms,
+                    "step_kernel_ms_first_iteration": per_iter[0],
+                    "step_kernel_ms_steady": float(np.mean(per_iter[10:])) if len(per_iter) > 12 else None,
+                    "step_kernel_ms_from": "a separate align, one iteration per call, HIP events around each launch "
+                                           "(the launch = step + reduction + solve)",
+                    "roofline": {"bound": "hbm", "achieved": algo / (step_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                 "unit": "GB/s", "frac": algo / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "traffic": pmc_traffic(pmc), "traffic_from": pmc_from,
+                                 "kernel": "icp_step_kernel<true>", "algorithmic_bytes_per_launch": algo}})
+    if comm is not None:
+        comm.close()
+    return out
+
+
+def bench_extras(env, tree, target, q_host, q_dev, stream):
+    """Side lines, each bounded to a few seconds: the other BASELINE configurations and the host-pointer path."""
+    capi, torch, world, rank, dev, barrier, max_over_ranks, log = (env[k] for k in (
+        "capi", "torch", "world", "rank", "dev", "barrier", "max_over_ranks", "log"))
+    ex = {}
+    # ---- configs[2]: radius search, r tuned to ~32 neighbours, variable-length (CSR) output in HBM
+    log("extras: radius search")
+    r = float((32 * 3 / (4 * np.pi * N_TARGET / 1024.0 ** 3)) ** (1 / 3))
+    lib = capi.load_library()
+    off = torch.empty(N_QUERY + 1, dtype=torch.int64, device=dev)
+    pi, pd, tot = C.c_void_p(), C.c_void_p(), C.c_uint64(0)
+
+    def radius_call():
+        rc = lib.pclmi_radius_dev(tree.h, q_dev.data_ptr(), N_QUERY, 16, r, 0, 1, off.data_ptr(), C.byref(pi),
+                                  C.byref(pd), C.byref(tot), stream)
+        assert rc == 0, lib.pclmi_last_error()
+        lib.pclmi_free_dev(pi)
+        lib.pclmi_free_dev(pd)
+
+    for _ in range(3):
+        radius_call()
+    capi.timing_enable(2 << capi.TIMER_RADIUS)
+    capi.timing_read(capi.TIMER_RADIUS, reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    reps = 10
+    for _ in range(reps):
+        radius_call()
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    r_ms, r_n = capi.timing_read(capi.TIMER_RADIUS, reset=True)
+    capi.timing_enable(False)
+    m_mean = tot.value / N_QUERY
+    r_algo = 16 * N_QUERY + 8 * (N_QUERY + 1) + 8 * tot.value + 16 * N_TARGET
+    trav_ms = r_ms / reps
+    ex["radius_1m"] = {"workload": "configs[2]: 1M-point target, 1M queries per GPU, r = %.3f (mean %.1f neighbours), "
+                                   "sorted CSR output" % (r, m_mean),
+                       "value": world * N_QUERY * reps / dt, "unit": "queries/s", "ms_per_call": dt / reps * 1e3,
+                       "roofline": {"bound": "hbm", "kernel": "radius traversal (count + provisional rows)",
+                                    "kernel_ms": trav_ms, "algorithmic_bytes_per_call": r_algo,
+                                    "achieved": r_algo / (dt / reps) / 1e9, "achieved_note": "whole call",
+                                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": r_algo / (dt / reps) / 1e9 / HBM_PEAK_GBS, "traffic": None}}
+    # ---- configs[4]: this GPU's share of the 100M-query k = 32 sweep on the 10M-point target
+    log("extras: configs[4] sweep (10M-point tree build)")
+    from pcl_amd import sweep
+    big = uniform_cloud(10_000_000, SEED_T, 0, 2048)
+    t0 = time.time()
+    tree10 = capi.Tree(big)
+    build10 = time.time() - t0
+    lo, hi = sweep.rank_slice(100_000_000, rank if world <= 8 else rank % 8, 8)
+    share = hi - lo
+    qs = torch.from_numpy(uniform_cloud(share, SEED_Q + 100 + rank, 0, 2048)).pin_memory()
+    k32 = 32
+    oi = torch.empty((share, k32), dtype=torch.int32, device=dev)
+    od = torch.empty((share, k32), dtype=torch.float32, device=dev)
+    log("extras: configs[4] sweep (%d queries in 4M batches)" % share)
+    sweep.knn_sweep(tree10, qs, k32, batch=4_000_000, device=dev, out=(oi, od))  # warm-up
+    capi.timing_enable(2 << capi.TIMER_KNN)
+    capi.timing_read(capi.TIMER_KNN, reset=True)
+    barrier()
+    tm = {}
+    t0 = time.perf_counter()
+    sweep.knn_sweep(tree10, qs, k32, batch=4_000_000, device=dev, out=(oi, od), timings=tm)
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    s_ms, s_n = capi.timing_read(capi.TIMER_KNN, reset=True)
+    # the same share uploaded in the same 4M batches but searched in ONE call (all its queries ordered together)
+    sweep.knn_sweep(tree10, qs, k32, batch=4_000_000, device=dev, out=(oi, od), resident=True)
+    capi.timing_read(capi.TIMER_KNN, reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    sweep.knn_sweep(tree10, qs, k32, batch=4_000_000, device=dev, out=(oi, od), resident=True)
+    barrier()
+    dt_res = max_over_ranks(time.perf_counter() - t0)
+    res_ms, res_n = capi.timing_read(capi.TIMER_KNN, reset=True)
+    capi.timing_enable(False)
+    s_algo = share * (16 + 8 * k32) + 16 * 10_000_000
+    ex["knn32_10m"] = {"workload": "configs[4]: 10M-point target, one GPU's share (%d of 100M queries), k = 32, queries "
+                                   "uploaded in 4M batches overlapped with the search, results kept in HBM" % share,
+                       "value": world * share / dt, "unit": "queries/s", "seconds_per_share": dt,
+                       "tree_build_s": round(build10, 3),
+                       "one_search_over_the_share": {"value": world * share / dt_res, "unit": "queries/s",
+                                                     "seconds_per_share": dt_res, "kernel_ms": res_ms,
+                                                     "launches": int(res_n),
+                                                     "frac": s_algo / (res_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if res_ms else None,
+                                                     "note": "same uploads, one pclmi_knn_dev_async over all 12.5M "
+                                                             "queries (sweep.knn_sweep resident=True)"},
+                       "roofline": {"bound": "hbm", "kernel": tree10.knn_kernel_name(k32, 4_000_000),
+                                    "kernel_ms": s_ms, "launches": int(s_n), "algorithmic_bytes": s_algo,
+                                    "bytes_per_query": s_algo / share,
+                                    "achieved": s_algo / (s_ms * 1e-3) / 1e9 if s_ms else None, "peak": HBM_PEAK_GBS,
+                                    "unit": "GB/s", "frac": s_algo / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if s_ms else None,
+                                    "traffic": None}}
+    del oi, od, qs
+    tree10.close()
+    if rank == 0:
+        # ---- host-pointer path: PCIe-inclusive rate and single-query latency (the reference's per-point call)
+        log("extras: host-pointer path")
+        tree.knn(q_host, K)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            tree.knn(q_host, K)
+        pcie = 3 * N_QUERY / (time.perf_counter() - t0)
+        one = np.ascontiguousarray(q_host[:2000])
+        oi1 = np.empty((1, K), np.int32)
+        od1 = np.empty((1, K), np.float32)
+        ke = C.c_int(0)
+        for i in range(200):
+            lib.pclmi_knn(tree.h, one[i].ctypes.data, 1, 12, K, oi1.ctypes.data, od1.ctypes.data, C.byref(ke))
+        t0 = time.perf_counter()
+        for i in range(2000):
+            lib.pclmi_knn(tree.h, one[i].ctypes.data, 1, 12, K, oi1.ctypes.data, od1.ctypes.data, C.byref(ke))
+        single_us = (time.perf_counter() - t0) / 2000 * 1e6
+        ex["host_pointer_path"] = {"knn_pcie_inclusive_qps": pcie,
+                                   "knn_pcie_inclusive_note": "pclmi_knn, 1M queries, k = 16, pageable host buffers: "
+                                                              "16 MB up + 128 MB down per call",
+                                   "knn_single_query_us": single_us,
+                                   "knn_single_query_note": "pclmi_knn with nq = 1 (what pcl::KdTreeFLANN::"
+                                                            "nearestKSearch calls), k = 16, through ctypes"}
+    if world == 1:
+        # ---- ICP with the reference's default RANSAC rejection step (icp.h:104: 1000 trials) on a bounded number
+        #      of iterations: host-driven, one synchronisation per trial
+        log("extras: ICP with RANSAC rejection")
+        tgt, src, T0 = icp_clouds()
+        t2 = capi.Tree(tgt)
+        p = capi.icp_default_params()
+        p.max_iterations, p.ransac_iterations, p.max_correspondence_distance = 5, 1000, 25.0
+        p.ransac_outlier_threshold = 0.5
+        capi.icp_align(t2, src, p)
+        p.max_iterations = 1
+        t0 = time.perf_counter()
+        capi.icp_align(t2, src, p)
+        dt1 = time.perf_counter() - t0  # set-up (upload, Hilbert ordering) + one iteration
+        p.max_iterations = 5
+        t0 = time.perf_counter()
+        rc, T, _, st = capi.icp_align(t2, src, p)
+        dt = time.perf_counter() - t0
+        ex["icp_ransac_on"] = {"workload": "configs[3] clouds, ransac_iterations = 1000 (adaptive stop), inlier "
+                                           "threshold 0.5, one GPU, pclmi_icp_align; per-iteration time = (5-iteration "
+                                           "align - 1-iteration align) / 4, so set-up cancels",
+                               "ms_per_iteration": (dt - dt1) / 4 * 1e3, "align_5_iterations_ms": dt * 1e3,
+                               "iterations": st.iterations,
+                               "last_inliers": st.last_inliers, "status": rc}
+        t2.close()
+    return ex
 
 
 def cpu_baseline(target, q_host, idx, d2):
-    """Times the oracle's FLANN-style kd-tree (CPU restatement, kind = "port") on this box's cores."""
+    """Times the oracle's FLANN-style kd-tree (CPU restatement, kind = "port") on this box's cores, compiled here
+    with the flags SURVEY 8d names (-O3 -march=native; contraction stays off: same arithmetic as the checker)."""
+    cores = len(os.sched_getaffinity(0))
+    if os.environ.get("OMP_NUM_THREADS", "").isdigit():
+        cores = min(cores, int(os.environ["OMP_NUM_THREADS"]))  # the box's CPU share
+    flags = "-O2 (prebuilt checker)"
+    try:
+        so = os.path.join(tempfile.mkdtemp(prefix="pclmi_oracle_"), "liboracle_native.so")
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-std=c11", "-ffp-contract=off", "-fopenmp", "-fPIC",
+                               "-shared", "-o", so, os.path.join(ROOT, "oracle", "pcl_oracle.c"), "-lm"], timeout=120)
+        os.environ["PCL_ORACLE_LIB"] = so
+        flags = "-O3 -march=native -ffp-contract=off -fopenmp"
+    except Exception as e:  # noqa: BLE001
+        print("bench.py: native oracle build failed (%r); timing the prebuilt -O2 checker" % (e,), file=sys.stderr)
     from oracle import pcl_oracle as orc
-    cores = min(16, len(os.sched_getaffinity(0)))
     tree = orc.Tree(target)
-    reps = 6  # ~10 core-seconds of CPU work on 16 cores
+    reps = 6  # ~10 core-seconds of CPU work per pass on 16 cores
     nq = len(q_host)
     orc.Tree.knn(tree, q_host[:20000], K, nthreads=cores)  # thread-pool warm-up
     t0 = time.perf_counter()
@@ -346,9 +626,10 @@ def cpu_baseline(target, q_host, idx, d2):
     t1 = time.perf_counter()
     tree.knn(q_host[:200_000], K, nthreads=1)
     dt1 = time.perf_counter() - t1
-    return {"value": reps * nq / dt, "unit": "queries/s", "cores": cores, "kind": "port",
+    return {"value": reps * nq / dt, "unit": "queries/s", "cores": cores, "kind": "port", "flags": flags,
             "sample": "all %d queries x %d passes, FLANN-style kd-tree (leaf 15), OpenMP over queries" % (nq, reps),
-            "single_thread_value": 200_000 / dt1, "gpu_matches_cpu_bitexact_on_20000": parity}
+            "single_thread_value": 200_000 / dt1, "single_query_us": dt1 / 200_000 * 1e6,
+            "gpu_matches_cpu_bitexact_on_20000": parity}
 
 
 if __name__ == "__main__":

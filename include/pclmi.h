@@ -116,6 +116,9 @@ int pclmi_knn_dev(const pclmi_tree *t, const float *d_queries, size_t nq, size_t
 int pclmi_knn_dev_async(const pclmi_tree *t, const float *d_queries, size_t nq, size_t q_stride_bytes,
                         int k, int32_t *d_idx, float *d_d2, void *stream);
 
+/* Name of the traversal kernel a batch of nq queries with this k is dispatched to (for measurement reports). */
+const char *pclmi_knn_kernel_name(const pclmi_tree *t, size_t nq, int k);
+
 /* Allocation-free variant of pclmi_knn_dev_async.  It has NO counterpart in the reference: it exists for callers
  * that cannot call hipMalloc - code under HIP graph capture, tight serving loops, harnesses that forbid allocation.
  * Same kernels and results; the scratch of the query-ordering pass lives in a file-scope device array of the

@@ -54,7 +54,9 @@ def build(force=False):
 def lib():
     global _LIB
     if _LIB is None:
-        so = _HERE / "liboracle.so"
+        # PCL_ORACLE_LIB: another build of the same source (bench.py's cpu_baseline leg compiles one with
+        # -O3 -march=native on the box it runs on: a -march=native library built elsewhere may not run there)
+        so = Path(os.environ.get("PCL_ORACLE_LIB") or (_HERE / "liboracle.so"))
         if not so.exists():
             build()
         L = C.CDLL(str(so))

@@ -72,6 +72,7 @@ SIGNATURES = {
                                       C.c_void_p]),
     "pclmi_knn_dev_noalloc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p,
                                         C.c_void_p, C.c_void_p]),
+    "pclmi_knn_kernel_name": (C.c_char_p, [C.c_void_p, C.c_size_t, C.c_int]),
     "pclmi_radius": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_double, C.c_uint32, C.c_int,
                                C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "pclmi_radius_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_double, C.c_uint32, C.c_int,
@@ -261,6 +262,9 @@ class Tree:
     def knn_dev(self, q_ptr, nq, q_stride_bytes, k, idx_ptr, d2_ptr, stream=None):
         """Device pointers (ints) in / out; row pitch of the outputs is min(k, len(tree))."""
         _check(load_library().pclmi_knn_dev(self.h, q_ptr, nq, q_stride_bytes, k, idx_ptr, d2_ptr, stream))
+
+    def knn_kernel_name(self, k, nq):
+        return load_library().pclmi_knn_kernel_name(self.h, nq, k).decode()
 
     def knn_dev_async(self, q_ptr, nq, q_stride_bytes, k, idx_ptr, d2_ptr, stream=None):
         """As knn_dev, but only enqueues on `stream` (pclmi_knn_dev_async)."""

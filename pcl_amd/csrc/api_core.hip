@@ -520,6 +520,11 @@ void pclmi_tree_destroy(pclmi_tree *t) {
 
 size_t pclmi_tree_size(const pclmi_tree *t) { return t ? t->n : 0; }
 
+const char *pclmi_knn_kernel_name(const pclmi_tree *t, size_t nq, int k) {
+  if (!t || k <= 0) return "";
+  return knn_kernel_name(t, nq, (size_t)k > t->n ? (int)t->n : k);
+}
+
 int pclmi_knn_dev(const pclmi_tree *t, const float *d_q, size_t nq, size_t q_stride_bytes, int k, int32_t *d_idx,
                   float *d_d2, void *stream) {
   int k_eff = 0;

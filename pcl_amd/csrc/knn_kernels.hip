@@ -766,6 +766,22 @@ static bool knn_sparse(const pclmi_tree *t, size_t nq) {
   return forced ? forced == 2 : nq * ratio < t->n;
 }
 
+#define PCLMI_STR2(x) #x
+#define PCLMI_STR(x) PCLMI_STR2(x)
+// the kernel launch_knn picks for a batch (the same rules, for reports: bench.py names the kernel it timed)
+const char *knn_kernel_name(const pclmi_tree *t, size_t nq, int k_eff) {
+  if (k_eff <= 1) return "knn1_union_kernel<4> / knn1_lane_kernel<4>";
+  if (k_eff <= 32 && knn_sparse(t, nq))
+    return k_eff <= 4 ? "knn_lane_ix_kernel<4,32>" : k_eff <= 8 ? "knn_lane_ix_kernel<8,32>"
+           : k_eff <= 16 ? "knn_lane_ix_kernel<16,40>" : "knn_lane_ix_kernel<32,64>";
+  if (k_eff <= 2) return "knn_union_ix_kernel<2,16,1>";
+  if (k_eff <= 4) return "knn_union_ix_kernel<4,16,1>";
+  if (k_eff <= 8) return "knn_union_ix_kernel<8," PCLMI_STR(PCLMI_IX8) ",1>";
+  if (k_eff <= 16) return "knn_union_ix_kernel<16," PCLMI_STR(PCLMI_IX16) ",1>";
+  if (k_eff <= 32) return "knn_union_ix_kernel<32," PCLMI_STR(PCLMI_IX32) ",1>";
+  return "knn_heap_kernel";
+}
+
 int launch_knn(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, size_t qsf,
                const int32_t *order, int k_eff, int32_t *d_idx, float *d_d2, hipStream_t s) {
   if (nq == 0 || k_eff <= 0) return PCLMI_OK;

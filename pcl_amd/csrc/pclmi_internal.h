@@ -198,6 +198,7 @@ void build_host_tree(const float *pts, const int32_t *ext, size_t n, HostTree *o
 int launch_morton_order(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq,
                         size_t q_stride_f, const float *bb_lo, const float *bb_hi, hipStream_t s,
                         const int32_t **d_order, bool stable = false);
+const char *knn_kernel_name(const pclmi_tree *t, size_t nq, int k_eff);
 int launch_knn(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, size_t q_stride_f,
                const int32_t *d_order, int k_eff, int32_t *d_idx, float *d_d2, hipStream_t s);
 

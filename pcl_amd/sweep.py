@@ -17,9 +17,15 @@ def rank_slice(n_total, rank, world):
     return lo, min(n_total, lo + per)
 
 
-def knn_sweep(tree, queries, k, batch=4_000_000, device=None, out=None, timings=None):
+def knn_sweep(tree, queries, k, batch=4_000_000, device=None, out=None, timings=None, resident=False):
     """queries: (n, 3 | 4) float32 host array (numpy, or a pinned torch tensor).  Returns (idx, d2) CUDA tensors
-    [n, k_eff] resident in HBM.  timings (dict, optional) receives the wall time of the pipeline in seconds."""
+    [n, k_eff] resident in HBM.  timings (dict, optional) receives the wall time of the pipeline in seconds.
+
+    resident=False: every uploaded batch is searched on its own while the next one uploads (bounded device memory
+    for the queries: two batches).  resident=True: the batches are uploaded into one device array and searched in ONE
+    call - a GPU's whole share fits HBM many times over (12.5M queries = 150 MB), and one call orders ALL its queries
+    along the Hilbert curve, so a wavefront's 64 queries are 3x closer together than in a 4M batch: the traversal
+    kernel runs ~1.6x faster per query on the 10M-point target, which outweighs the lost upload overlap."""
     import time
 
     import torch
@@ -42,6 +48,8 @@ def knn_sweep(tree, queries, k, batch=4_000_000, device=None, out=None, timings=
     if n == 0 or k_eff == 0:
         return idx, d2
     batch = max(1, min(batch, n))
+    if resident:
+        return _sweep_resident(tree, q, k, batch, dev, idx, d2, timings)
     stage = [torch.empty((batch, w), dtype=torch.float32, device=dev) for _ in range(2)]
     up, run = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
     uploaded = [torch.cuda.Event() for _ in range(2)]
@@ -66,4 +74,25 @@ def knn_sweep(tree, queries, k, batch=4_000_000, device=None, out=None, timings=
     if timings is not None:
         timings["seconds"] = time.perf_counter() - t0
     cur.wait_stream(run)
+    return idx, d2
+
+
+def _sweep_resident(tree, q, k, batch, dev, idx, d2, timings):
+    import time
+
+    import torch
+    n, w = q.shape
+    qd = torch.empty((n, w), dtype=torch.float32, device=dev)
+    up = torch.cuda.Stream(device=dev)
+    cur = torch.cuda.current_stream(dev)
+    up.wait_stream(cur)
+    t0 = time.perf_counter()
+    with torch.cuda.stream(up):
+        for a in range(0, n, batch):
+            qd[a:a + batch].copy_(q[a:a + batch], non_blocking=True)
+        tree.knn_dev_async(qd.data_ptr(), n, w * 4, k, idx.data_ptr(), d2.data_ptr(), up.cuda_stream)
+    up.synchronize()
+    if timings is not None:
+        timings["seconds"] = time.perf_counter() - t0
+    cur.wait_stream(up)
     return idx, d2

@@ -52,6 +52,12 @@ def test_c5_one_gpu_share_streamed():
         rec = (sq[..., 0] + sq[..., 1]) + sq[..., 2]
         assert torch.equal(rec.view(torch.int32), d.view(torch.int32)), "every distance is the fp32 distance of its point"
         del nb, df, sq, rec
+    # the same share searched in one call (resident=True): identical rows
+    ri, rd = sweep.knn_sweep(tree, q, K, batch=BATCH, device=dev, resident=True, timings=tm)
+    torch.cuda.synchronize()
+    print("configs[4] share, one search: %.3f s = %.3e queries/s" % (tm["seconds"], n / tm["seconds"]))
+    assert torch.equal(ri, idx) and torch.equal(rd.view(torch.int32), d2.view(torch.int32))
+    del ri, rd
     # a batch through the synchronous entry point gives the same rows
     m = 300_000
     a = 4_100_000  # straddles the first batch boundary region of the sweep's second batch
@@ -76,12 +82,14 @@ def test_sweep_small_and_ragged():
     tree = capi.Tree(pts)
     for n, batch in ((0, 10), (1, 10), (1000, 333), (70_001, 33_000)):
         q = util.uniform_cloud(n, 2 + n, 0, 10)
-        idx, d2 = sweep.knn_sweep(tree, q, 5, batch=batch, device=dev)
-        torch.cuda.synchronize()
-        if n == 0:
-            assert idx.shape == (0, 5)
-            continue
-        ri, rd = tree.knn(q, 5)
-        assert np.array_equal(idx.cpu().numpy(), ri) and np.array_equal(d2.cpu().numpy().view(np.int32), rd.view(np.int32))
+        for resident in (False, True):
+            idx, d2 = sweep.knn_sweep(tree, q, 5, batch=batch, device=dev, resident=resident)
+            torch.cuda.synchronize()
+            if n == 0:
+                assert idx.shape == (0, 5)
+                continue
+            ri, rd = tree.knn(q, 5)
+            assert np.array_equal(idx.cpu().numpy(), ri)
+            assert np.array_equal(d2.cpu().numpy().view(np.int32), rd.view(np.int32))
     assert sweep.rank_slice(10, 3, 4) == (9, 10) and sweep.rank_slice(10, 0, 4) == (0, 3)
     tree.close()
