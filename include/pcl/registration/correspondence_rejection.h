@@ -181,14 +181,22 @@ class CorrespondenceRejectorVarTrimmed : public CorrespondenceRejector {
   void getRemainingCorrespondences(const pcl::Correspondences &original, pcl::Correspondences &remaining) override {
     pcl::Correspondences tmp(original.size());
     size_t n_out = 0;
-    const int rc = pclmi_reject_var_trimmed(in(original), original.size(), min_ratio_, max_ratio_, lambda_, out(tmp), &n_out,
-                                            &factor_, &trimmed_distance_);
+    // by_distance_ == false: the reference as shipped (its loop reads the sorted scratch array, so the first
+    // #(sorted < trimmed) inputs are kept); setSelectByOwnDistance(true) judges every pair by its own distance
+    const int rc = pclmi_reject_var_trimmed(in(original), original.size(), min_ratio_, max_ratio_, lambda_,
+                                            by_distance_ ? 1 : 0, out(tmp), &n_out, &factor_, &trimmed_distance_);
     finish(rc, n_out, tmp);
     remaining.swap(tmp);
   }
 
  protected:
   double trimmed_distance_, factor_, min_ratio_, max_ratio_, lambda_;
+  bool by_distance_ = false;
+
+ public:
+  /** \brief Not in the reference: select by each correspondence's own distance (the documented intent) instead of
+    * reproducing the reference's as-shipped selection (correspondence_rejection_var_trimmed.hpp:69-76). */
+  void setSelectByOwnDistance(bool on) { by_distance_ = on; }
 };
 
 // correspondence_rejection_sample_consensus.h / impl/_sample_consensus.hpp:44-110

@@ -191,8 +191,10 @@ int pclmi_correspondences_reciprocal(const pclmi_tree *target, const pclmi_tree 
 int pclmi_reject_distance(const pclmi_correspondence *in, size_t n, float max_distance,
                           pclmi_correspondence *out, size_t *n_out);
 /* _median_distance.hpp:44-69: keep distance <= median * factor, median = the n/2-th smallest
- * distance (*median, nullable).  The reference's loop reads the nth_element-permuted scratch array
- * instead of the correspondences' own distances; the documented intent is implemented here. */
+ * distance (*median, nullable).  KNOWN DEVIATION: the reference's loop (:62-65) reads the scratch array that
+ * std::nth_element has permuted, so WHICH correspondences it keeps depends on the standard library's permutation
+ * (the count does not); that cannot be reproduced portably, so every correspondence is judged by its own distance
+ * here (the documented intent).  Same count, same median as the reference. */
 int pclmi_reject_median(const pclmi_correspondence *in, size_t n, double factor,
                         pclmi_correspondence *out, size_t *n_out, double *median);
 /* _one_to_one.hpp:42-67: sort by (index_match, distance), keep the nearest query of every match;
@@ -203,12 +205,15 @@ int pclmi_reject_one_to_one(const pclmi_correspondence *in, size_t n, pclmi_corr
  * distances, sorted ascending; input returned unchanged when that is >= n. */
 int pclmi_reject_trimmed(const pclmi_correspondence *in, size_t n, float overlap_ratio,
                          unsigned min_correspondences, pclmi_correspondence *out, size_t *n_out);
-/* _var_trimmed.hpp:44-107: trim factor = argmin of the FRMS curve over [min_ratio, max_ratio]
- * (defaults 0.05, 0.95, lambda 0.95), keep distance < the int(n * factor)-th smallest distance;
- * input order kept (documented intent, see pclmi_reject_median). */
+/* _var_trimmed.hpp:44-107: trim factor = first argmin of the FRMS curve over [min_ratio, max_ratio] (defaults 0.05,
+ * 0.95, lambda 0.95), trimmed distance = the int(n * factor)-th smallest distance.
+ * by_distance == 0: the reference AS SHIPPED - its selection loop (:69-76) reads dists[i], an array that
+ * optimizeInlierRatio has sorted in place (:87), so the FIRST #(sorted distances < trimmed) inputs are kept, in input
+ * order, whatever their own distances; by_distance != 0: the documented intent - keep the correspondences whose OWN
+ * distance is below the trimmed distance, input order kept.  Same count either way. */
 int pclmi_reject_var_trimmed(const pclmi_correspondence *in, size_t n, double min_ratio,
-                             double max_ratio, double lambda, pclmi_correspondence *out, size_t *n_out,
-                             double *trim_factor, double *trimmed_distance);
+                             double max_ratio, double lambda, int by_distance, pclmi_correspondence *out,
+                             size_t *n_out, double *trim_factor, double *trimmed_distance);
 /* _sample_consensus.hpp:44-110: RANSAC over SampleConsensusModelRegistration (seed 12345) on the
  * pairs (src[index_query], tgt[index_match]); keeps the inliers of the best three-point model in
  * input order, best_T = that model.  Keeps everything (best_T = identity) when no model is found. */
@@ -217,6 +222,34 @@ int pclmi_reject_sample_consensus(const float *src, size_t n_src, size_t src_str
                                   const pclmi_correspondence *in, size_t n, double inlier_threshold,
                                   int max_iterations, pclmi_correspondence *out, size_t *n_out,
                                   float best_T[16]);
+
+/* Device-resident forms of the modular pipeline (test/registration/test_registration_api.cpp:62-347 chain:
+ * CorrespondenceEstimation -> CorrespondenceRejector* -> TransformationEstimationSVD): clouds and correspondence
+ * records stay in HBM between the stages, work is enqueued on `stream`, scratch comes from a pooled per-device
+ * workspace (no hipMalloc in the steady state).  d_in / d_out are DEVICE arrays (d_out capacity n, in != out);
+ * only the stage's count (and its scalars) come back: each call waits for its own work on `stream` to read them.
+ * Semantics as the host-pointer forms above. */
+int pclmi_correspondences_dev(const pclmi_tree *target, const float *d_src, size_t n_src, size_t stride_bytes,
+                              const int32_t *d_src_indices, size_t n_indices, double max_distance,
+                              pclmi_correspondence *d_out, size_t *n_out, void *stream);
+int pclmi_reject_distance_dev(const pclmi_correspondence *d_in, size_t n, float max_distance,
+                              pclmi_correspondence *d_out, size_t *n_out, void *stream);
+int pclmi_reject_median_dev(const pclmi_correspondence *d_in, size_t n, double factor, pclmi_correspondence *d_out,
+                            size_t *n_out, double *median, void *stream);
+int pclmi_reject_one_to_one_dev(const pclmi_correspondence *d_in, size_t n, pclmi_correspondence *d_out,
+                                size_t *n_out, void *stream);
+int pclmi_reject_trimmed_dev(const pclmi_correspondence *d_in, size_t n, float overlap_ratio,
+                             unsigned min_correspondences, pclmi_correspondence *d_out, size_t *n_out,
+                             void *stream);
+int pclmi_reject_var_trimmed_dev(const pclmi_correspondence *d_in, size_t n, double min_ratio, double max_ratio,
+                                 double lambda, int by_distance, pclmi_correspondence *d_out, size_t *n_out,
+                                 double *trim_factor, double *trimmed_distance, void *stream);
+/* TransformationEstimationSVD::estimateRigidTransformation(src, tgt, correspondences, T)
+ * (impl/transformation_estimation_svd.hpp:101-111) with clouds and correspondences in HBM: pairs
+ * (src[index_query], tgt[index_match]); the 24 fp64 sums are reduced on the GPU, the 3x3 solve runs on the host. */
+int pclmi_estimate_rigid_svd_dev(const float *d_src, size_t n_src, size_t src_stride_bytes, const float *d_tgt,
+                                 size_t n_tgt, size_t tgt_stride_bytes, const pclmi_correspondence *d_corr, size_t n,
+                                 float T[16], void *stream);
 
 /* Rigid transform from paired points ------------------------------------------------
  * Replaces TransformationEstimationSVD::estimateRigidTransformation

@@ -838,10 +838,13 @@ int64_t orc_reject_trimmed(const orc_corr *in, int64_t n, float overlap, unsigne
 /* correspondence_rejection_var_trimmed.hpp:44-107.  optimizeInlierRatio sorts the distances and
  * takes the argmin of FRMS_i = (1 / ratio_i^lambda)^2 * (1 / id_i) * (lower_sum + sorted[min_el + i])
  * (elementwise, as the reference's Eigen expression reads - not a cumulative sum); the kept set is
- * distance < sorted[int(n * factor)].  As in orc_reject_median the selection reads each
- * correspondence's own distance (the reference's loop indexes the sorted scratch array instead). */
+ * distance < sorted[int(n * factor)].
+ * by_distance == 0: AS SHIPPED - the selection loop (:69-76) reads dists[i] of the scratch array that
+ * optimizeInlierRatio sorted in place (:87), so original[i] is kept iff sorted[i] < trimmed: the first
+ * #(sorted < trimmed) inputs.  by_distance != 0: each correspondence's own distance (the documented intent). */
 int64_t orc_reject_var_trimmed(const orc_corr *in, int64_t n, double min_ratio, double max_ratio,
-                               double lambda, orc_corr *out, double *factor_out, double *trimmed_out) {
+                               double lambda, int by_distance, orc_corr *out, double *factor_out,
+                               double *trimmed_out) {
   if (factor_out) *factor_out = 0.0;
   if (trimmed_out) *trimmed_out = 0.0;
   if (n == 0) return 0;
@@ -870,12 +873,12 @@ int64_t orc_reject_var_trimmed(const orc_corr *in, int64_t n, double min_ratio, 
   int64_t pos = (int64_t)(int)((double)n * factor);
   if (pos >= n) pos = n - 1;
   double trimmed = d[pos];
-  free(d);
   if (factor_out) *factor_out = factor;
   if (trimmed_out) *trimmed_out = trimmed;
   int64_t c = 0;
   for (int64_t i = 0; i < n; ++i)
-    if ((double)in[i].distance < trimmed) out[c++] = in[i];
+    if ((by_distance ? (double)in[i].distance : d[i]) < trimmed) out[c++] = in[i]; /* :72 */
+  free(d);
   return c;
 }
 

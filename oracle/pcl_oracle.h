@@ -102,7 +102,8 @@ int64_t orc_reject_one_to_one(const orc_corr *in, int64_t n, orc_corr *out);
 int64_t orc_reject_trimmed(const orc_corr *in, int64_t n, float overlap, unsigned min_corr,
                            orc_corr *out);
 int64_t orc_reject_var_trimmed(const orc_corr *in, int64_t n, double min_ratio, double max_ratio,
-                               double lambda, orc_corr *out, double *factor, double *trimmed_distance);
+                               double lambda, int by_distance, orc_corr *out, double *factor,
+                               double *trimmed_distance);
 /* RANSAC over SampleConsensusModelRegistration, seed 12345
  * (sample_consensus/include/pcl/sample_consensus/impl/ransac.hpp:44-133,
  *  impl/sac_model_registration.hpp, sac_model.h:87-97,166-198,401-412).

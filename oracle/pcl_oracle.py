@@ -90,8 +90,8 @@ def lib():
         L.orc_reject_trimmed.restype = c_i64
         L.orc_reject_trimmed.argtypes = [C.c_void_p, c_i64, C.c_float, C.c_uint, C.c_void_p]
         L.orc_reject_var_trimmed.restype = c_i64
-        L.orc_reject_var_trimmed.argtypes = [C.c_void_p, c_i64, C.c_double, C.c_double, C.c_double, C.c_void_p,
-                                             C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.orc_reject_var_trimmed.argtypes = [C.c_void_p, c_i64, C.c_double, C.c_double, C.c_double, C.c_int,
+                                             C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.orc_ransac_registration.restype = c_i64
         L.orc_ransac_registration.argtypes = [c_f32p, c_i64, C.c_int, c_f32p, c_i64, C.c_int, c_i32p, c_i32p,
                                               c_i64, C.c_double, C.c_int, c_i32p, c_f32p, C.POINTER(C.c_int)]
@@ -311,12 +311,12 @@ def reject_trimmed(corr, overlap=0.5, min_corr=0):
     return out[:n].copy()
 
 
-def reject_var_trimmed(corr, min_ratio=0.05, max_ratio=0.95, lam=0.95):
+def reject_var_trimmed(corr, min_ratio=0.05, max_ratio=0.95, lam=0.95, by_distance=False):
     corr = np.ascontiguousarray(corr, CORR_DTYPE)
     out = np.zeros(len(corr), CORR_DTYPE)
     f, d = C.c_double(0), C.c_double(0)
-    n = lib().orc_reject_var_trimmed(corr.ctypes.data, len(corr), min_ratio, max_ratio, lam, out.ctypes.data,
-                                     C.byref(f), C.byref(d))
+    n = lib().orc_reject_var_trimmed(corr.ctypes.data, len(corr), min_ratio, max_ratio, lam, int(by_distance),
+                                     out.ctypes.data, C.byref(f), C.byref(d))
     return out[:n].copy(), f.value, d.value
 
 

@@ -89,8 +89,21 @@ SIGNATURES = {
     "pclmi_reject_one_to_one": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t)]),
     "pclmi_reject_trimmed": (C.c_int, [C.c_void_p, C.c_size_t, C.c_float, C.c_uint, C.c_void_p,
                                        C.POINTER(C.c_size_t)]),
-    "pclmi_reject_var_trimmed": (C.c_int, [C.c_void_p, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_void_p,
-                                           C.POINTER(C.c_size_t), c_f64p, c_f64p]),
+    "pclmi_reject_var_trimmed": (C.c_int, [C.c_void_p, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_int,
+                                           C.c_void_p, C.POINTER(C.c_size_t), c_f64p, c_f64p]),
+    "pclmi_correspondences_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
+                                            C.c_double, C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p]),
+    "pclmi_reject_distance_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_float, C.c_void_p, C.POINTER(C.c_size_t),
+                                            C.c_void_p]),
+    "pclmi_reject_median_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_double, C.c_void_p, C.POINTER(C.c_size_t),
+                                          c_f64p, C.c_void_p]),
+    "pclmi_reject_one_to_one_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p]),
+    "pclmi_reject_trimmed_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_float, C.c_uint, C.c_void_p,
+                                           C.POINTER(C.c_size_t), C.c_void_p]),
+    "pclmi_reject_var_trimmed_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_int,
+                                               C.c_void_p, C.POINTER(C.c_size_t), c_f64p, c_f64p, C.c_void_p]),
+    "pclmi_estimate_rigid_svd_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t,
+                                               C.c_void_p, C.c_size_t, c_f32p, C.c_void_p]),
     "pclmi_reject_sample_consensus": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
                                                 C.c_size_t, C.c_void_p, C.c_size_t, C.c_double, C.c_int, C.c_void_p,
                                                 C.POINTER(C.c_size_t), c_f32p]),
@@ -414,9 +427,11 @@ def reject_trimmed(corr, overlap=0.5, min_corr=0):
     return _rej(load_library().pclmi_reject_trimmed, corr, overlap, min_corr)
 
 
-def reject_var_trimmed(corr, min_ratio=0.05, max_ratio=0.95, lam=0.95):
+def reject_var_trimmed(corr, min_ratio=0.05, max_ratio=0.95, lam=0.95, by_distance=False):
+    """by_distance=False: the reference as shipped (the first #(sorted < trimmed) inputs); True: by own distance."""
     f, d = C.c_double(0), C.c_double(0)
-    out = _rej(load_library().pclmi_reject_var_trimmed, corr, min_ratio, max_ratio, lam, extra=(C.byref(f), C.byref(d)))
+    out = _rej(load_library().pclmi_reject_var_trimmed, corr, min_ratio, max_ratio, lam, int(by_distance),
+               extra=(C.byref(f), C.byref(d)))
     return out, f.value, d.value
 
 

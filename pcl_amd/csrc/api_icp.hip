@@ -123,6 +123,34 @@ int pclmi_estimate_rigid_svd(const float *src, size_t n_src, size_t src_stride_b
   return solve_rigid_from_sums(h, T);
 }
 
+int pclmi_estimate_rigid_svd_dev(const float *d_src, size_t n_src, size_t src_stride_bytes, const float *d_tgt,
+                                 size_t n_tgt, size_t tgt_stride_bytes, const pclmi_correspondence *d_corr, size_t n,
+                                 float T[16], void *stream) {
+  PCLMI_CHECK(d_src && d_tgt && T, PCLMI_ERR_INVALID, "NULL argument");
+  PCLMI_CHECK(src_stride_bytes >= 12 && src_stride_bytes % 4 == 0 && tgt_stride_bytes >= 12 &&
+                  tgt_stride_bytes % 4 == 0,
+              PCLMI_ERR_INVALID, "bad stride");
+  PCLMI_CHECK(pclmi_device_count() > 0, PCLMI_ERR_NO_DEVICE, "no HIP device visible: libpclmi has no CPU fallback");
+  set_identity(T);
+  PCLMI_CHECK(n > 0 && d_corr, PCLMI_ERR_NOT_ENOUGH, "no point pairs");
+  PCLMI_CHECK(n < ((size_t)1 << 31), PCLMI_ERR_UNSUPPORTED, "more than 2^31-1 correspondences");
+  (void)n_src;
+  (void)n_tgt;
+  hipStream_t s = (hipStream_t)stream;
+  // partial sums + the 24 results: a small pooled block (the result-buffer cache recycles it from call to call)
+  const size_t bytes = ((size_t)pair_reduce_blocks(n) + 1) * PCLMI_ICP_NSUMS * sizeof(double);
+  double *buf = (double *)dev_cache_get(bytes);
+  if (!buf) return PCLMI_ERR_OOM;
+  double *sums = buf + (size_t)pair_reduce_blocks(n) * PCLMI_ICP_NSUMS;
+  launch_corr_reduce(d_src, src_stride_bytes / 4, d_tgt, tgt_stride_bytes / 4, d_corr, n, buf, sums, s);
+  double h[PCLMI_ICP_NSUMS];
+  hipError_t e = hipMemcpyAsync(h, sums, sizeof(h), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  dev_cache_put(buf);
+  if (e != hipSuccess) return hip_fail(e, "rigid estimate", __FILE__, __LINE__);
+  return solve_rigid_from_sums(h, T);
+}
+
 // ---- correspondence estimation -------------------------------------------------------------
 static int nn1_of(const pclmi_tree *tree, const float *pts, size_t n_rows, size_t stride_bytes,
                   const int32_t *rows, size_t n_sel, std::vector<int32_t> &idx, std::vector<float> &d2) {

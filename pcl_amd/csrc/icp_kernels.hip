@@ -486,6 +486,37 @@ __global__ __launch_bounds__(64 * PR_WPB) void pair_reduce_kernel(const float4 *
   block_reduce_store<NS, PR_WPB>(acc, lds, lane, wib, partials + (size_t)blockIdx.x * NS);
 }
 
+// the same sums over a correspondence list with the clouds in their caller layout (strided rows):
+// pairs (src[index_query], tgt[index_match]); moments about the first pair's target point
+__global__ __launch_bounds__(64 * PR_WPB) void corr_reduce_kernel(const float *__restrict__ src, int src_stride_f,
+                                                                   const float *__restrict__ tgt, int tgt_stride_f,
+                                                                   const pclmi_correspondence *__restrict__ corr, int n,
+                                                                   double *__restrict__ partials) {
+  __shared__ double lds[PR_WPB][NS];
+  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  const float *t0 = tgt + (size_t)corr[0].index_match * tgt_stride_f;
+  const double ox = t0[0], oy = t0[1], oz = t0[2];
+  double acc[NS];
+#pragma unroll
+  for (int j = 0; j < NS; ++j) acc[j] = 0.0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const pclmi_correspondence c = corr[i];
+    const float *p = src + (size_t)c.index_query * src_stride_f;
+    const float *q = tgt + (size_t)c.index_match * tgt_stride_f;
+    const double sx = (double)p[0] - ox, sy = (double)p[1] - oy, sz = (double)p[2] - oz;
+    const double tx = (double)q[0] - ox, ty = (double)q[1] - oy, tz = (double)q[2] - oz;
+    acc[0] += 1.0;
+    acc[1] += sx; acc[2] += sy; acc[3] += sz;
+    acc[4] += tx; acc[5] += ty; acc[6] += tz;
+    acc[7] += sx * tx; acc[8] += sx * ty; acc[9] += sx * tz;
+    acc[10] += sy * tx; acc[11] += sy * ty; acc[12] += sy * tz;
+    acc[13] += sz * tx; acc[14] += sz * ty; acc[15] += sz * tz;
+    acc[18] += 1.0;
+    acc[19] += ox; acc[20] += oy; acc[21] += oz;
+  }
+  block_reduce_store<NS, PR_WPB>(acc, lds, lane, wib, partials + (size_t)blockIdx.x * NS);
+}
+
 // RANSAC support -------------------------------------------------------------------------------
 // countWithinDistance / selectWithinDistance (sample_consensus/.../impl/sac_model_registration.hpp
 // :131-224): pairs with |T s - t|^2 < thr2 in fp32.  flags (nullable) receives 0/1 per pair.
@@ -666,6 +697,15 @@ void launch_pair_reduce(const float4 *src, const int *sidx, const float4 *tgt, c
   const unsigned blocks = pair_reduce_blocks(n);
   hipLaunchKernelGGL(pair_reduce_kernel, dim3(blocks), dim3(64 * PR_WPB), 0, s, src, sidx, tgt, tidx, flags, (int)n,
                      origin[0], origin[1], origin[2], d_partials);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(NS), dim3(256), 0, s, d_partials, (int)blocks, (size_t)NS, (size_t)1,
+                     d_sums);
+}
+
+void launch_corr_reduce(const float *src, size_t src_stride_f, const float *tgt, size_t tgt_stride_f,
+                        const pclmi_correspondence *corr, size_t n, double *d_partials, double *d_sums, hipStream_t s) {
+  const unsigned blocks = pair_reduce_blocks(n);
+  hipLaunchKernelGGL(corr_reduce_kernel, dim3(blocks), dim3(64 * PR_WPB), 0, s, src, (int)src_stride_f, tgt,
+                     (int)tgt_stride_f, corr, (int)n, d_partials);
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(NS), dim3(256), 0, s, d_partials, (int)blocks, (size_t)NS, (size_t)1,
                      d_sums);
 }

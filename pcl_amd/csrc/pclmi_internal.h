@@ -282,6 +282,8 @@ unsigned pair_reduce_blocks(size_t n);
 void launch_pair_reduce(const float4 *src, const int *sidx, const float4 *tgt, const int *tidx,
                         const unsigned char *flags, size_t n, const double origin[3], double *d_partials,
                         double *d_sums, hipStream_t s);
+void launch_corr_reduce(const float *src, size_t src_stride_f, const float *tgt, size_t tgt_stride_f,
+                        const pclmi_correspondence *corr, size_t n, double *d_partials, double *d_sums, hipStream_t s);
 void launch_moment_reduce(const float4 *src, const int *sidx, size_t n, double *d_partials, double *d_sums,
                           hipStream_t s);
 void launch_count_within(const float4 *src, const int *sidx, const float4 *tgt, const int *tidx, size_t n,

@@ -564,6 +564,13 @@ TEST(RegistrationAPI) {
   rej_var.setInputCorrespondences(corr);
   rej_var.getCorrespondences(res);
   EXPECT(res.size() < corr->size() && rej_var.getTrimFactor() >= 0.05 && rej_var.getTrimFactor() <= 0.95);
+  // as shipped (correspondence_rejection_var_trimmed.hpp:69-76 reads the sorted scratch array): the first inputs
+  for (size_t i = 0; i < res.size(); ++i)
+    EXPECT(res[i].index_query == (*corr)[i].index_query && res[i].index_match == (*corr)[i].index_match);
+  const size_t n_shipped = res.size();
+  rej_var.setSelectByOwnDistance(true);  // the documented intent: same count, chosen by their own distances
+  rej_var.getCorrespondences(res);
+  EXPECT(res.size() == n_shipped);
   for (size_t i = 0; i < res.size(); ++i) EXPECT(res[i].distance < rej_var.getTrimmedDistance());
 
   // TransformationEstimationSVD on the reciprocal pairs (:325-347)

@@ -41,9 +41,13 @@ def test_bun_rejectors_golden(capi, orc):
     md, med = capi.reject_median(corr, 0.5)
     omd, omed = orc.reject_median(corr, 0.5)
     assert med == omed and np.array_equal(md, omd)
-    vt, f, d = capi.reject_var_trimmed(corr)
-    ovt, of, od = orc.reject_var_trimmed(corr)
-    assert (f, d) == (of, od) and np.array_equal(vt, ovt)
+    for by_distance in (False, True):  # the reference as shipped (first cnt inputs) / by own distance
+        vt, f, d = capi.reject_var_trimmed(corr, by_distance=by_distance)
+        ovt, of, od = orc.reject_var_trimmed(corr, by_distance=by_distance)
+        assert (f, d) == (of, od) and np.array_equal(vt, ovt)
+    vs, _, ds = capi.reject_var_trimmed(corr)
+    assert np.array_equal(vs, corr[:len(vs)]), "as shipped: the first #(sorted < trimmed) inputs, in input order"
+    assert len(vs) == int((np.sort(corr["distance"]).astype(np.float64) < ds).sum())
 
 
 def _random_corr(n, seed, n_match):
@@ -69,9 +73,10 @@ def test_rejectors_vs_oracle_random(capi, orc, n):
     for ov, mc in ((0.5, 0), (0.9, 0), (0.1, 5), (1.0, 0), (0.0, 0)):
         assert np.array_equal(capi.reject_trimmed(c, ov, mc), orc.reject_trimmed(c, ov, mc))
     for a, b, lam in ((0.05, 0.95, 0.95), (0.2, 0.6, 0.5)):
-        g, gf, gd = capi.reject_var_trimmed(c, a, b, lam)
-        o, of, od = orc.reject_var_trimmed(c, a, b, lam)
-        assert (gf, gd) == (of, od) and np.array_equal(g, o)
+        for by_distance in (False, True):
+            g, gf, gd = capi.reject_var_trimmed(c, a, b, lam, by_distance)
+            o, of, od = orc.reject_var_trimmed(c, a, b, lam, by_distance)
+            assert (gf, gd) == (of, od) and np.array_equal(g, o)
 
 
 def test_rejectors_empty(capi):
