@@ -6,6 +6,9 @@
 #ifndef PCLMI_FACADE_REGISTRATION_ICP_H_
 #define PCLMI_FACADE_REGISTRATION_ICP_H_
 
+#include <cmath>
+#include <limits>
+
 #include <pcl/registration/registration.h>
 #include <pcl/registration/transformation_estimation_svd.h>
 
@@ -41,6 +44,13 @@ class IterativeClosestPoint : public Registration<PointSource, PointTarget> {
     svd_estimation_ = transformation_estimation_.get();
   }
 
+  /** \brief Not in the reference: run align() over the ranks of a pclmi_comm (one process per GPU, every process
+    * calls align() with the same clouds and parameters): the source is sharded over the ranks, every iteration
+    * exchanges the 24 moment sums inside the step kernel (pclmi_icp_align_sharded).  RANSAC rejection must be off
+    * (setRANSACIterations(0)).  Every rank ends with the same final transformation; rows of the output cloud that
+    * belong to other ranks are the input moved by the final transformation in one step.  NULL detaches. */
+  void setComm(pclmi_comm *comm) { comm_ = comm; }
+
   // statistics of the last align()
   int getNumberOfIterations() const { return nr_iterations_; }
   const pclmi_icp_stats &getLastStats() const { return stats_; }
@@ -55,6 +65,9 @@ class IterativeClosestPoint : public Registration<PointSource, PointTarget> {
       return;
     }
     if (!tree_->getDeviceTree() || output.points.empty()) return;
+    if (Base::point_representation_ && !Base::point_representation_->isTrivial())
+      PCL_WARN("[pcl::%s::computeTransformation] the point representation applies to the target tree only: the "
+               "correspondence loop reads the source's raw x, y, z\n", getClassName().c_str());
     pclmi_icp_params p;
     pclmi_icp_default_params(&p);
     p.max_iterations = max_iterations_;
@@ -67,11 +80,22 @@ class IterativeClosestPoint : public Registration<PointSource, PointTarget> {
     std::vector<float> aligned(output.points.size() * 4);
     // `output` already holds input[indices] (Registration::align); the library sets w = 1, applies the
     // guess (icp.hpp:60-66) and iterates
-    const int rc = pclmi_icp_align(&p, tree_->getDeviceTree(), reinterpret_cast<const float *>(output.points.data()),
-                                   output.points.size(), sizeof(PointSource), guess.isIdentity() ? nullptr : guess.data(),
-                                   final_transformation_.data(), aligned.data(), &stats_);
+    const bool sharded = comm_ && pclmi_comm_size(comm_) > 1;
+    if (sharded)
+      for (size_t i = 0; i < aligned.size(); ++i) aligned[i] = std::numeric_limits<float>::quiet_NaN();
+    const float *src_xyz = reinterpret_cast<const float *>(output.points.data());
+    const int rc =
+        sharded ? pclmi_icp_align_sharded(&p, tree_->getDeviceTree(), src_xyz, output.points.size(), sizeof(PointSource),
+                                          guess.isIdentity() ? nullptr : guess.data(), comm_,
+                                          final_transformation_.data(), aligned.data(), &stats_)
+                : pclmi_icp_align(&p, tree_->getDeviceTree(), src_xyz, output.points.size(), sizeof(PointSource),
+                                  guess.isIdentity() ? nullptr : guess.data(), final_transformation_.data(),
+                                  aligned.data(), &stats_);
     nr_iterations_ = stats_.iterations;
     converged_ = stats_.converged != 0;
+    // transformation_ = the last iteration's incremental transform (icp.hpp:171), previous_transformation_ the one
+    // before it is not kept by the device loop: getLastIncrementalTransformation() is what callers read
+    for (int i = 0; i < 16; ++i) transformation_.data()[i] = stats_.last_transform[i];
     if (rc == PCLMI_ERR_NOT_ENOUGH) {  // icp.hpp:103-108
       PCL_ERROR("[pcl::%s::computeTransformation] Not enough correspondences found. Relax your threshold parameters.\n",
                 getClassName().c_str());
@@ -80,6 +104,19 @@ class IterativeClosestPoint : public Registration<PointSource, PointTarget> {
       return;
     }
     for (size_t i = 0; i < output.points.size(); ++i) {
+      if (sharded && std::isnan(aligned[i * 4 + 0])) {  // another rank's row: the input moved by the final transform
+        const float x = output.points[i].x, y = output.points[i].y, z = output.points[i].z;
+        const float *F = final_transformation_.data();
+        if (std::isfinite(x) && std::isfinite(y) && std::isfinite(z)) {
+          aligned[i * 4 + 0] = ((F[0] * x + F[1] * y) + F[2] * z) + F[3];
+          aligned[i * 4 + 1] = ((F[4] * x + F[5] * y) + F[6] * z) + F[7];
+          aligned[i * 4 + 2] = ((F[8] * x + F[9] * y) + F[10] * z) + F[11];
+        } else {
+          aligned[i * 4 + 0] = x;
+          aligned[i * 4 + 1] = y;
+          aligned[i * 4 + 2] = z;
+        }
+      }
       output.points[i].x = aligned[i * 4 + 0];
       output.points[i].y = aligned[i * 4 + 1];
       output.points[i].z = aligned[i * 4 + 2];
@@ -93,6 +130,7 @@ class IterativeClosestPoint : public Registration<PointSource, PointTarget> {
 
   const void *svd_estimation_;
   pclmi_icp_stats stats_;
+  pclmi_comm *comm_ = nullptr;
 };
 
 }  // namespace pcl

@@ -289,6 +289,8 @@ typedef struct {
   int last_inliers;         /* pairs used for the last transform (after RANSAC) */
   double fitness_delta;     /* mean(d_now - d_prev) of the last iteration (registration.hpp:60-68) */
   double transform_delta;   /* sum |T - T_prev| of the last iteration (icp.hpp:194) */
+  float last_transform[16]; /* the last iteration's incremental transform (transformation_, icp.hpp:171):
+                               Registration::getLastIncrementalTransformation; identity before any iteration */
 } pclmi_icp_stats;
 
 void pclmi_icp_default_params(pclmi_icp_params *p);

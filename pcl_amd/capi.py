@@ -48,6 +48,7 @@ class IcpStats(C.Structure):
         ("last_inliers", C.c_int),
         ("fitness_delta", C.c_double),
         ("transform_delta", C.c_double),
+        ("last_transform", C.c_float * 16),
     ]
 
 

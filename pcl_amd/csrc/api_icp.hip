@@ -479,6 +479,7 @@ int pclmi_icp_state(pclmi_icp_ctx *c, float final_T[16], pclmi_icp_stats *stats)
     stats->last_inliers = h.last_pairs;
     stats->fitness_delta = h.fit;
     stats->transform_delta = h.tdelta;
+    std::memcpy(stats->last_transform, h.T, sizeof(h.T));
   }
   if (h.status == PCLMI_ERR_COMM) {
     set_error("the exchange with the other ranks timed out in iteration %d", h.iterations + 1);
@@ -560,6 +561,7 @@ int pclmi_icp_align_sharded(const pclmi_icp_params *p, const pclmi_tree *target,
   if (!rc) rc = pclmi_icp_set_comm(c, comm);
   pclmi_icp_stats st;
   std::memset(&st, 0, sizeof(st));
+  set_identity(st.last_transform);
   int enqueued = 0;
   while (!rc) {
     // every rank enqueues the same chunks: the criteria see identical sums, so all ranks stop in the same iteration
@@ -765,7 +767,10 @@ int pclmi_icp_align(const pclmi_icp_params *p, const pclmi_tree *target, const f
                     pclmi_icp_stats *stats) {
   PCLMI_CHECK(p && target && final_T, PCLMI_ERR_INVALID, "NULL argument");
   set_identity(final_T);
-  if (stats) std::memset(stats, 0, sizeof(*stats));
+  if (stats) {
+    std::memset(stats, 0, sizeof(*stats));
+    set_identity(stats->last_transform);
+  }
   PCLMI_CHECK(n_src > 0 && src, PCLMI_ERR_INVALID, "empty source cloud");
   pclmi_icp_ctx *c = nullptr;
   RC(pclmi_icp_begin(target, src, n_src, stride_bytes, guess, &c));
@@ -845,6 +850,7 @@ int pclmi_icp_align(const pclmi_icp_params *p, const pclmi_tree *target, const f
     stats->last_inliers = (int)used;
     stats->fitness_delta = fit;
     stats->transform_delta = tdelta;
+    std::memcpy(stats->last_transform, T, sizeof(T));
   }
   int rc2 = pclmi_icp_end(c, aligned);
   return rc ? rc : rc2;

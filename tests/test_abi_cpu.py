@@ -84,7 +84,7 @@ def test_default_params_match_reference_defaults():
     assert p.transformation_epsilon == 0.0 and p.ransac_outlier_threshold == 0.05
     assert p.euclidean_fitness_epsilon == -np.finfo(np.float64).max
     assert p.max_correspondence_distance == np.sqrt(np.finfo(np.float64).max)
-    assert C.sizeof(capi.IcpParams) == 48 and C.sizeof(capi.IcpStats) == 32
+    assert C.sizeof(capi.IcpParams) == 48 and C.sizeof(capi.IcpStats) == 96  # 32 + last_transform[16]
 
 
 def test_point_normal_needs_no_gpu_and_matches_the_reference_golden():
