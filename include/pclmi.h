@@ -379,6 +379,34 @@ int pclmi_icp_align_sharded(const pclmi_icp_params *p, const pclmi_tree *target,
                             size_t stride_bytes, const float *guess, pclmi_comm *comm, float final_T[16],
                             float *aligned, pclmi_icp_stats *stats);
 
+/* Point-to-plane ICP ------------------------------------------------------------------------
+ * IterativeClosestPoint with setTransformationEstimation (TransformationEstimationPointToPlaneLLS)
+ * (registration/include/pcl/registration/registration.h:140-160, impl/icp.hpp:171 calling
+ * impl/transformation_estimation_point_to_plane_lls.hpp:83-101,141-245): the same correspondence loop, but every
+ * iteration solves the linearised point-to-plane problem min sum ((R s + t - d) . n)^2 over the pairs instead of the
+ * SVD fit.  The step kernel adds each pair's row to the 21 + 6 sums of the 6x6 normal equations (fp64, the fp32
+ * products of :186-188 and :219 as the reference writes them), the launch's last workgroup solves them and builds the
+ * transform (constructTransformationMatrix, :118-139) - still ONE kernel per iteration.
+ *   tgt_normals: one normal per row of the cloud the target tree was built from (n_tgt >= rows of that cloud);
+ *                pairs whose target normal is not finite are skipped by the estimator (:158-174) but still count as
+ *                correspondences (icp.hpp:93-98).
+ *   src_normals: nullable; the reference also skips pairs whose SOURCE normal is not finite (it never uses its
+ *                value, and transformPointCloud leaves it alone): pass the source's normals to reproduce that, NULL
+ *                when they are all finite or absent.
+ * pclmi_icp_set_point_to_plane switches a context (before its first step); its sums are then
+ * PCLMI_ICP_NSUMS_PLANE doubles: [0..20] upper triangle of ATA row by row, [21..26] ATb, [27] n_pairs,
+ * [28] sum min(d2, thr2), [29] sum (d_now - d_prev), [30] n_points, [31] zero - pclmi_icp_step_dev writes that many,
+ * pclmi_icp_step (24 host doubles) refuses such a context.
+ * pclmi_icp_align_point_to_plane = pclmi_icp_align (comm == NULL or one rank) / pclmi_icp_align_sharded with this
+ * estimator; the RANSAC rejection step is supported on one GPU (the refit of icp.hpp:171 on the inliers). */
+#define PCLMI_ICP_NSUMS_PLANE 32
+int pclmi_icp_set_point_to_plane(pclmi_icp_ctx *ctx, const float *tgt_normals, size_t n_tgt, size_t tn_stride_bytes,
+                                 const float *src_normals, size_t n_src, size_t sn_stride_bytes);
+int pclmi_icp_align_point_to_plane(const pclmi_icp_params *p, const pclmi_tree *target, const float *src, size_t n_src,
+                                   size_t stride_bytes, const float *src_normals, size_t sn_stride_bytes,
+                                   const float *tgt_normals, size_t n_tgt, size_t tn_stride_bytes, const float *guess,
+                                   pclmi_comm *comm, float final_T[16], float *aligned, pclmi_icp_stats *stats);
+
 /* Multi-GPU exchange (one process per GPU on one node) -----------------------------------
  * The reference is single-process (no counterpart); this is the exchange step of the sharded ICP loop
  * (one all-reduce of the PCLMI_ICP_NSUMS fp64 moments per iteration) kept BELOW the C ABI, so that C++

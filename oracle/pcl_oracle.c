@@ -1067,9 +1067,16 @@ void orc_icp_default_params(orc_icp_params *p) {
   p->svd_scalar_double = 0;
 }
 
-int orc_icp_align(const orc_icp_params *p, const float *src, int64_t ns, int ss, const float *tgt,
-                  int64_t nt, int ts, const float *guess, float final_T[16], float *out,
-                  orc_icp_stats *stats, int nthreads) {
+void orc_estimate_point_to_plane_lls(const float *src, int ss, const float *sn, int sns, const int32_t *sidx,
+                                     const float *tgt, int ts, const float *tn, int tns, const int32_t *tidx,
+                                     int64_t n, float T[16]);
+
+/* tn != NULL: the loop runs with TransformationEstimationPointToPlaneLLS (registration.h:140-160 setTransformationEstimation,
+ * icp.hpp:171); tn / sn are the normals of the target / source rows (sn nullable; the source normals are not moved by
+ * transformPointCloud, icp.hpp:174, and the estimator only tests them for finiteness). */
+static int icp_align_core(const orc_icp_params *p, const float *src, int64_t ns, int ss, const float *sn, int sns,
+                          const float *tgt, int64_t nt, int ts, const float *tn, int tns, const float *guess,
+                          float final_T[16], float *out, orc_icp_stats *stats, int nthreads) {
   float T[16], Tprev[16];
   mat4_identity(final_T);
   mat4_identity(T);
@@ -1144,7 +1151,9 @@ int orc_icp_align(const orc_icp_params *p, const float *src, int64_t ns, int ss,
       }
     }
     if (ngood < p->min_correspondences) { rc = -2; break; } /* icp.hpp:153-159 */
-    if (p->svd_scalar_double) /* icp.hpp:171 */
+    if (tn) /* icp.hpp:171 with the point-to-plane estimator */
+      orc_estimate_point_to_plane_lls(out, 4, sn, sns, sgood, target, 4, tn, tns, tgood, ngood, T);
+    else if (p->svd_scalar_double) /* icp.hpp:171 */
       orc_estimate_rigid_svd_f64(out, 4, sgood, target, 4, tgood, ngood, T);
     else
       orc_estimate_rigid_svd(out, 4, sgood, target, 4, tgood, ngood, T);
@@ -1170,6 +1179,20 @@ int orc_icp_align(const orc_icp_params *p, const float *src, int64_t ns, int ss,
   orc_tree_free(tree);
   free(target);
   return rc;
+}
+
+int orc_icp_align(const orc_icp_params *p, const float *src, int64_t ns, int ss, const float *tgt,
+                  int64_t nt, int ts, const float *guess, float final_T[16], float *out,
+                  orc_icp_stats *stats, int nthreads) {
+  return icp_align_core(p, src, ns, ss, NULL, 0, tgt, nt, ts, NULL, 0, guess, final_T, out, stats, nthreads);
+}
+
+int orc_icp_align_point_to_plane(const orc_icp_params *p, const float *src, int64_t ns, int ss, const float *sn,
+                                 int sns, const float *tgt, int64_t nt, int ts, const float *tn, int tns,
+                                 const float *guess, float final_T[16], float *out, orc_icp_stats *stats,
+                                 int nthreads) {
+  if (!tn) return -1;
+  return icp_align_core(p, src, ns, ss, sn, sns, tgt, nt, ts, tn, tns, guess, final_T, out, stats, nthreads);
 }
 
 double orc_fitness_score(const float *src, int64_t ns, int ss, const float *tgt, int64_t nt,

@@ -141,6 +141,16 @@ int orc_icp_align(const orc_icp_params *p, const float *src, int64_t ns, int sst
                   const float *tgt, int64_t nt, int tstride, const float *guess,
                   float final_T[16], float *aligned, orc_icp_stats *stats, int nthreads);
 
+/* The same loop with setTransformationEstimation (TransformationEstimationPointToPlaneLLS)
+ * (registration/include/pcl/registration/registration.h:140-160; icp.hpp:171 then calls
+ * impl/transformation_estimation_point_to_plane_lls.hpp:83-101,141-245 on the *_good index lists).
+ * tn: target normals (row i of tn belongs to row i of tgt); sn: source normals, nullable (only tested for
+ * finiteness, :158-174). */
+int orc_icp_align_point_to_plane(const orc_icp_params *p, const float *src, int64_t ns, int sstride,
+                                 const float *sn, int snstride, const float *tgt, int64_t nt, int tstride,
+                                 const float *tn, int tnstride, const float *guess, float final_T[16],
+                                 float *aligned, orc_icp_stats *stats, int nthreads);
+
 /* Registration::getFitnessScore(max_range) (impl/registration.hpp:71-109). */
 double orc_fitness_score(const float *src, int64_t ns, int sstride, const float *tgt,
                          int64_t nt, int tstride, const float final_T[16], double max_range);

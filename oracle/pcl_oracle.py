@@ -99,6 +99,10 @@ def lib():
         L.orc_icp_align.restype = C.c_int
         L.orc_icp_align.argtypes = [C.POINTER(IcpParams), c_f32p, c_i64, C.c_int, c_f32p, c_i64, C.c_int, c_f32p,
                                     c_f32p, c_f32p, C.POINTER(IcpStats), C.c_int]
+        L.orc_icp_align_point_to_plane.restype = C.c_int
+        L.orc_icp_align_point_to_plane.argtypes = [C.POINTER(IcpParams), c_f32p, c_i64, C.c_int, c_f32p, C.c_int,
+                                                   c_f32p, c_i64, C.c_int, c_f32p, C.c_int, c_f32p, c_f32p, c_f32p,
+                                                   C.POINTER(IcpStats), C.c_int]
         L.orc_fitness_score.restype = C.c_double
         L.orc_fitness_score.argtypes = [c_f32p, c_i64, C.c_int, c_f32p, c_i64, C.c_int, c_f32p, C.c_double]
         L.orc_estimate_point_to_plane_lls.argtypes = [c_f32p, C.c_int, c_f32p, C.c_int, c_i32p, c_f32p, C.c_int, c_f32p,
@@ -349,6 +353,22 @@ def icp_align(src, tgt, params=None, guess=None, nthreads=1):
     rc = lib().orc_icp_align(C.byref(p), _p(src, c_f32p), len(src), src.shape[1], _p(tgt, c_f32p), len(tgt),
                              tgt.shape[1], _p(g, c_f32p) if g is not None else None, _p(T, c_f32p),
                              _p(out, c_f32p), C.byref(st), nthreads)
+    return rc, T.reshape(4, 4), out, st
+
+
+def icp_align_point_to_plane(src, tgt, tgt_normals, params=None, guess=None, src_normals=None, nthreads=1):
+    """ICP with TransformationEstimationPointToPlaneLLS as the estimator (icp.hpp:171)."""
+    src, tgt, tn = _f32(src), _f32(tgt), _f32(tgt_normals)
+    sn = _f32(src_normals) if src_normals is not None else None
+    p = params or icp_default_params()
+    T = np.zeros(16, np.float32)
+    out = np.zeros((len(src), 4), np.float32)
+    st = IcpStats()
+    g = np.ascontiguousarray(guess, np.float32).reshape(16) if guess is not None else None
+    rc = lib().orc_icp_align_point_to_plane(
+        C.byref(p), _p(src, c_f32p), len(src), src.shape[1], _p(sn, c_f32p) if sn is not None else None,
+        sn.shape[1] if sn is not None else 0, _p(tgt, c_f32p), len(tgt), tgt.shape[1], _p(tn, c_f32p), tn.shape[1],
+        _p(g, c_f32p) if g is not None else None, _p(T, c_f32p), _p(out, c_f32p), C.byref(st), nthreads)
     return rc, T.reshape(4, 4), out, st
 
 

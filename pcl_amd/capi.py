@@ -13,6 +13,7 @@ _LIB = None
 
 STATUS = {0: "OK", 1: "INVALID", 2: "NO_DEVICE", 3: "HIP", 4: "OOM", 5: "UNSUPPORTED", 6: "NOT_ENOUGH", 7: "COMM"}
 ICP_NSUMS = 24
+ICP_NSUMS_PLANE = 32  # sums of a point-to-plane context (pclmi.h "Point-to-plane ICP")
 
 CORR_DTYPE = np.dtype([("index_query", np.int32), ("index_match", np.int32), ("distance", np.float32)])
 
@@ -146,6 +147,11 @@ SIGNATURES = {
     "pclmi_icp_shard_size": (C.c_size_t, [C.c_void_p]),
     "pclmi_icp_align_sharded": (C.c_int, [C.POINTER(IcpParams), C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t,
                                           c_f32p, C.c_void_p, c_f32p, C.c_void_p, C.POINTER(IcpStats)]),
+    "pclmi_icp_set_point_to_plane": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
+                                               C.c_size_t]),
+    "pclmi_icp_align_point_to_plane": (C.c_int, [C.POINTER(IcpParams), C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t,
+                                                 C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, c_f32p,
+                                                 C.c_void_p, c_f32p, C.c_void_p, C.POINTER(IcpStats)]),
     "pclmi_comm_begin": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_void_p]),
     "pclmi_comm_connect": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pclmi_comm_create_shm": (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]),
@@ -510,6 +516,30 @@ def icp_align_sharded(target_tree, src, comm, params=None, guess=None):
     return rc, T.reshape(4, 4), out, st
 
 
+def icp_align_point_to_plane(target_tree, src, tgt_normals, params=None, guess=None, src_normals=None, comm=None):
+    """pclmi_icp_align_point_to_plane: ICP with TransformationEstimationPointToPlaneLLS.  tgt_normals: one row per row
+    of the target cloud.  With a Comm of several ranks every rank passes the whole source and `aligned` holds the
+    rank's own rows (the others NaN).  Returns (status, T[4,4], aligned[n,4], stats)."""
+    lib = load_library()
+    s = _pts(src)
+    tn = _pts(tgt_normals)
+    sn = None if src_normals is None else _pts(src_normals)
+    p = params or icp_default_params()
+    T = np.zeros(16, np.float32)
+    sharded = comm is not None and comm.size > 1
+    out = np.full((len(s), 4), np.nan if sharded else 0.0, np.float32)
+    st = IcpStats()
+    g = None if guess is None else np.ascontiguousarray(guess, np.float32).reshape(16)
+    rc = lib.pclmi_icp_align_point_to_plane(
+        C.byref(p), target_tree.h, s.ctypes.data, len(s), s.shape[1] * 4, None if sn is None else sn.ctypes.data,
+        0 if sn is None else sn.shape[1] * 4, tn.ctypes.data, len(tn), tn.shape[1] * 4,
+        None if g is None else g.ctypes.data_as(c_f32p), None if comm is None else comm.h, T.ctypes.data_as(c_f32p),
+        out.ctypes.data, C.byref(st))
+    if rc not in (0, 6):
+        _check(rc)
+    return rc, T.reshape(4, 4), out, st
+
+
 def fitness_score(target_tree, src, T, max_range=float(np.finfo(np.float64).max)):
     s = _pts(src)
     Tm = np.ascontiguousarray(T, np.float32).reshape(16)
@@ -610,6 +640,15 @@ class IcpShard:
         """Attach a Comm: run_dev then exchanges the sums inside the step kernel (pclmi_icp_set_comm)."""
         _check(load_library().pclmi_icp_set_comm(self.h, None if comm is None else comm.h))
         self.comm = comm
+
+    def set_point_to_plane(self, tgt_normals, src_normals=None):
+        """Switch the context to TransformationEstimationPointToPlaneLLS (before the first step); its sums are then
+        ICP_NSUMS_PLANE doubles (pclmi_icp_set_point_to_plane)."""
+        tn = _pts(tgt_normals)
+        sn = None if src_normals is None else _pts(src_normals)
+        _check(load_library().pclmi_icp_set_point_to_plane(
+            self.h, tn.ctypes.data, len(tn), tn.shape[1] * 4, None if sn is None else sn.ctypes.data,
+            0 if sn is None else len(sn), 0 if sn is None else sn.shape[1] * 4))
 
     def step(self, max_correspondence_distance):
         sums = np.zeros(ICP_NSUMS, np.float64)

@@ -73,6 +73,16 @@ struct pclmi_icp_ctx {
   bool sharded = false;
   size_t n_full = 0;                // rows of the whole source
   std::vector<int> shard_rows;      // slot -> row of the whole source
+  // point-to-plane loop (pclmi_icp_set_point_to_plane)
+  bool plane = false;
+  DevBuf<float4> tn_rows;           // target normals by cloud row (RANSAC refit)
+  DevBuf<float4> tn_slot;           // target normals by bucket slot (step kernel)
+  DevBuf<unsigned char> src_skip;   // per slot: the source normal is not finite (allocated only when one is)
+  bool has_skip = false;
+  int nsums() const { return plane ? PCLMI_ICP_NSUMS_PLANE : PCLMI_ICP_NSUMS; }
+  int i_pairs() const { return plane ? 27 : 0; }
+  int i_fit() const { return plane ? 29 : 17; }
+  int i_points() const { return plane ? 30 : 18; }
 };
 
 extern "C" {
@@ -286,11 +296,11 @@ int pclmi_icp_begin_sharded(const pclmi_tree *target, const float *src, size_t n
   if (!(lo[0] <= hi[0])) lo[0] = lo[1] = lo[2] = hi[0] = hi[1] = hi[2] = 0.f;
   if ((rc = c->pts.alloc(n_src)) || (rc = c->order.alloc(n_src)) || (rc = c->inv.alloc(n_src)) ||
       (rc = c->nn.alloc(n_src)) || (rc = c->nn_slot.alloc(n_src)) || (rc = c->dist.alloc(n_src)) ||
-      (rc = c->partials.alloc((size_t)std::max(icp_step_blocks(n_src), pair_reduce_blocks(n_src)) * PCLMI_ICP_NSUMS)) ||
-      (rc = c->sums.alloc(PCLMI_ICP_NSUMS)))
+      (rc = c->partials.alloc((size_t)std::max(icp_step_blocks(n_src), pair_reduce_blocks(n_src)) * PCLMI_ICP_NSUMS_PLANE)) ||
+      (rc = c->sums.alloc(PCLMI_ICP_NSUMS_PLANE)))
     return fail(rc);
   c->groups = icp_step_groups(n_src);
-  if ((rc = c->gpart.alloc((size_t)c->groups * PCLMI_ICP_NSUMS)) || (rc = c->tickets.alloc(c->groups + 1))) return fail(rc);
+  if ((rc = c->gpart.alloc((size_t)c->groups * PCLMI_ICP_NSUMS_PLANE)) || (rc = c->tickets.alloc(c->groups + 1))) return fail(rc);
   if (hipMemsetAsync(c->tickets.p, 0, (c->groups + 1) * sizeof(unsigned int), c->stream) != hipSuccess)
     return fail(hip_fail(hipGetLastError(), "memset", __FILE__, __LINE__));
   {
@@ -384,7 +394,8 @@ static int icp_step_enqueue(pclmi_icp_ctx *c, double max_correspondence_distance
   tail.ngroups = (int)c->groups;
   if (fused && c->comm) tail.comm = comm_view(c->comm);
   launch_icp_step(c->tree, c->pts.p, c->n, c->pending, make_xf(c->T), thr2, c->nn.p, c->nn_slot.p, c->dist.p, c->origin,
-                  c->partials.p, s, c->dev_mode ? c->state.p : nullptr, c->stepped, tail);
+                  c->partials.p, s, c->dev_mode ? c->state.p : nullptr, c->stepped, tail,
+                  c->plane ? c->tn_slot.p : nullptr, c->has_skip ? c->src_skip.p : nullptr);
   c->pending = false;
   c->stepped = true;
   PCLMI_HIP(hipGetLastError());
@@ -395,11 +406,59 @@ int pclmi_icp_step_dev(pclmi_icp_ctx *c, double max_correspondence_distance, dou
   return icp_step_enqueue(c, max_correspondence_distance, d_sums, stream, false);
 }
 
+// h_sums: c->nsums() doubles
+static int icp_step_host(pclmi_icp_ctx *c, double max_correspondence_distance, double *h_sums) {
+  RC(pclmi_icp_step_dev(c, max_correspondence_distance, c->sums.p, nullptr));
+  PCLMI_HIP(hipMemcpyAsync(h_sums, c->sums.p, (size_t)c->nsums() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  PCLMI_HIP(hipStreamSynchronize(c->stream));
+  return PCLMI_OK;
+}
+
 int pclmi_icp_step(pclmi_icp_ctx *c, double max_correspondence_distance, double h_sums[PCLMI_ICP_NSUMS]) {
   PCLMI_CHECK(c && h_sums, PCLMI_ERR_INVALID, "NULL argument");
-  RC(pclmi_icp_step_dev(c, max_correspondence_distance, c->sums.p, nullptr));
-  PCLMI_HIP(hipMemcpyAsync(h_sums, c->sums.p, PCLMI_ICP_NSUMS * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  PCLMI_CHECK(!c->plane, PCLMI_ERR_UNSUPPORTED,
+              "a point-to-plane context produces PCLMI_ICP_NSUMS_PLANE sums: use pclmi_icp_step_dev / pclmi_icp_run_dev");
+  return icp_step_host(c, max_correspondence_distance, h_sums);
+}
+
+// TransformationEstimationPointToPlaneLLS inside the loop (pclmi.h "Point-to-plane ICP")
+int pclmi_icp_set_point_to_plane(pclmi_icp_ctx *c, const float *tgt_normals, size_t n_tgt, size_t tn_stride_bytes,
+                                 const float *src_normals, size_t n_src, size_t sn_stride_bytes) {
+  PCLMI_CHECK(c && tgt_normals, PCLMI_ERR_INVALID, "NULL argument");
+  PCLMI_CHECK(!c->stepped && !c->dev_mode, PCLMI_ERR_INVALID, "the estimator must be chosen before the first step");
+  PCLMI_CHECK(tn_stride_bytes >= 12 && tn_stride_bytes % 4 == 0 && (!src_normals || (sn_stride_bytes >= 12 && sn_stride_bytes % 4 == 0)),
+              PCLMI_ERR_INVALID, "bad stride");
+  PCLMI_CHECK(n_tgt >= c->tree->rows, PCLMI_ERR_INVALID, "%zu target normals for a target cloud of %zu rows", n_tgt,
+              (size_t)c->tree->rows);
+  PCLMI_CHECK(!src_normals || n_src == c->n_full, PCLMI_ERR_INVALID, "%zu source normals for a source of %zu rows", n_src,
+              c->n_full);
+  PCLMI_HIP(hipSetDevice(c->tree->device));
+  RC(upload_packed(tgt_normals, c->tree->rows, tn_stride_bytes, nullptr, 0, c->tn_rows, c->stream));
+  RC(c->tn_slot.alloc((size_t)c->tree->M * kLeafSize));
+  launch_normals_to_slots(c->tree, c->tn_rows.p, c->tn_slot.p, c->stream);
+  PCLMI_HIP(hipGetLastError());
+  c->has_skip = false;
+  if (src_normals && c->n) {
+    // per slot: is the source normal of that row finite?  (the normals never change: transformPointCloud moves x, y, z)
+    std::vector<int> rows(c->n);
+    if (c->sharded) rows = c->shard_rows;
+    else PCLMI_HIP(hipMemcpyAsync(rows.data(), c->order.p, c->n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    PCLMI_HIP(hipStreamSynchronize(c->stream));
+    std::vector<unsigned char> skip(c->n, 0);
+    const size_t sf = sn_stride_bytes / 4;
+    bool any = false;
+    for (size_t i = 0; i < c->n; ++i) {
+      const float *m = src_normals + (size_t)rows[i] * sf;
+      if (!std::isfinite(m[0]) || !std::isfinite(m[1]) || !std::isfinite(m[2])) skip[i] = 1, any = true;
+    }
+    if (any) {
+      RC(c->src_skip.alloc(c->n));
+      PCLMI_HIP(hipMemcpyAsync(c->src_skip.p, skip.data(), c->n, hipMemcpyHostToDevice, c->stream));
+      c->has_skip = true;
+    }
+  }
   PCLMI_HIP(hipStreamSynchronize(c->stream));
+  c->plane = true;
   return PCLMI_OK;
 }
 
@@ -427,7 +486,7 @@ int pclmi_icp_solve_dev(pclmi_icp_ctx *c, const double *d_sums, void *stream) {
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
   c->user_stream = stream ? s : nullptr;
   c->dev_mode = true;
-  launch_icp_solve(d_sums, c->state.p, s);
+  launch_icp_solve(d_sums, c->state.p, s, c->plane);
   PCLMI_HIP(hipGetLastError());
   return PCLMI_OK;
 }
@@ -543,38 +602,6 @@ int pclmi_icp_end(pclmi_icp_ctx *c, float *aligned) {
 }
 
 size_t pclmi_icp_shard_size(const pclmi_icp_ctx *c) { return c ? c->n : 0; }
-
-int pclmi_icp_align_sharded(const pclmi_icp_params *p, const pclmi_tree *target, const float *src, size_t n_src,
-                            size_t stride_bytes, const float *guess, pclmi_comm *comm, float final_T[16],
-                            float *aligned, pclmi_icp_stats *stats) {
-  PCLMI_CHECK(p && target && final_T && comm, PCLMI_ERR_INVALID, "NULL argument");
-  set_identity(final_T);
-  if (stats) std::memset(stats, 0, sizeof(*stats));
-  PCLMI_CHECK(n_src > 0 && src, PCLMI_ERR_INVALID, "empty source cloud");
-  PCLMI_CHECK(p->ransac_iterations <= 0 || pclmi_comm_size(comm) == 1, PCLMI_ERR_UNSUPPORTED,
-              "the RANSAC rejection step needs the global pair list: set ransac_iterations = 0 for a sharded align");
-  if (pclmi_comm_size(comm) == 1) return pclmi_icp_align(p, target, src, n_src, stride_bytes, guess, final_T, aligned, stats);
-  pclmi_icp_ctx *c = nullptr;
-  RC(pclmi_icp_begin_sharded(target, src, n_src, stride_bytes, guess, pclmi_comm_rank(comm), pclmi_comm_size(comm), &c));
-  if (guess && !is_identity(guess)) std::memcpy(final_T, guess, 16 * sizeof(float));
-  int rc = pclmi_icp_set_criteria(c, p);
-  if (!rc) rc = pclmi_icp_set_comm(c, comm);
-  pclmi_icp_stats st;
-  std::memset(&st, 0, sizeof(st));
-  set_identity(st.last_transform);
-  int enqueued = 0;
-  while (!rc) {
-    // every rank enqueues the same chunks: the criteria see identical sums, so all ranks stop in the same iteration
-    const int chunk = std::max(1, std::min(16, p->max_iterations - enqueued));
-    if ((rc = pclmi_icp_run_dev(c, p->max_correspondence_distance, chunk, nullptr))) break;
-    enqueued += chunk;
-    rc = pclmi_icp_state(c, final_T, &st);
-    if (st.converged) break;
-  }
-  if (stats) *stats = st;
-  int rc2 = pclmi_icp_end(c, aligned);
-  return rc ? rc : rc2;
-}
 
 // ---- RANSAC rejection as invoked from ICP (icp.hpp:113-150) ------------------------------------
 // Host control flow restates RandomSampleConsensus::computeModel
@@ -716,7 +743,7 @@ struct RansacScratch {
 };
 
 int ransac_icp(pclmi_icp_ctx *c, RansacScratch &rs, const pclmi_icp_params *p, int64_t *n_inliers,
-               double sums_out[PCLMI_ICP_NSUMS]) {
+               double *sums_out /* c->nsums() */) {
   *n_inliers = -1;
   const size_t n = c->n;
   hipStream_t s = c->stream;
@@ -752,9 +779,13 @@ int ransac_icp(pclmi_icp_ctx *c, RansacScratch &rs, const pclmi_icp_params *p, i
                  p->ransac_iterations, rs.flags.p, s, &have, Tbest, &inl, nullptr));
   if (!have) return PCLMI_OK;
   // the sums of the inlier pairs, for the refit (icp.hpp:171 on the *_good index lists)
-  launch_pair_reduce(c->pts.p, rs.pair_slot.p, cloud, rs.pair_tgt.p, rs.flags.p, cnt, c->origin, c->partials.p,
-                     c->sums.p, s);
-  PCLMI_HIP(hipMemcpyAsync(sums_out, c->sums.p, PCLMI_ICP_NSUMS * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (c->plane)
+    launch_pair_reduce_plane(c->pts.p, rs.pair_slot.p, cloud, rs.pair_tgt.p, c->tn_rows.p,
+                             c->has_skip ? c->src_skip.p : nullptr, rs.flags.p, cnt, c->partials.p, c->sums.p, s);
+  else
+    launch_pair_reduce(c->pts.p, rs.pair_slot.p, cloud, rs.pair_tgt.p, rs.flags.p, cnt, c->origin, c->partials.p,
+                       c->sums.p, s);
+  PCLMI_HIP(hipMemcpyAsync(sums_out, c->sums.p, (size_t)c->nsums() * sizeof(double), hipMemcpyDeviceToHost, s));
   PCLMI_HIP(hipStreamSynchronize(s));
   *n_inliers = inl;
   return PCLMI_OK;
@@ -762,9 +793,19 @@ int ransac_icp(pclmi_icp_ctx *c, RansacScratch &rs, const pclmi_icp_params *p, i
 
 }  // namespace
 
-int pclmi_icp_align(const pclmi_icp_params *p, const pclmi_tree *target, const float *src, size_t n_src,
-                    size_t stride_bytes, const float *guess, float final_T[16], float *aligned,
-                    pclmi_icp_stats *stats) {
+namespace {
+
+struct PlaneArgs {
+  const float *src_normals;
+  size_t sn_stride;
+  const float *tgt_normals;
+  size_t n_tgt, tn_stride;
+};
+
+// Registration::align for both estimators, on one GPU or over the ranks of `comm`
+int align_core(const pclmi_icp_params *p, const pclmi_tree *target, const float *src, size_t n_src, size_t stride_bytes,
+               const float *guess, pclmi_comm *comm, const PlaneArgs *plane, float final_T[16], float *aligned,
+               pclmi_icp_stats *stats) {
   PCLMI_CHECK(p && target && final_T, PCLMI_ERR_INVALID, "NULL argument");
   set_identity(final_T);
   if (stats) {
@@ -772,19 +813,30 @@ int pclmi_icp_align(const pclmi_icp_params *p, const pclmi_tree *target, const f
     set_identity(stats->last_transform);
   }
   PCLMI_CHECK(n_src > 0 && src, PCLMI_ERR_INVALID, "empty source cloud");
+  const int world = comm ? pclmi_comm_size(comm) : 1;
+  PCLMI_CHECK(p->ransac_iterations <= 0 || world == 1, PCLMI_ERR_UNSUPPORTED,
+              "the RANSAC rejection step needs the global pair list: set ransac_iterations = 0 for a sharded align");
   pclmi_icp_ctx *c = nullptr;
-  RC(pclmi_icp_begin(target, src, n_src, stride_bytes, guess, &c));
+  RC(pclmi_icp_begin_sharded(target, src, n_src, stride_bytes, guess, world > 1 ? pclmi_comm_rank(comm) : 0, world, &c));
   if (guess && !is_identity(guess)) std::memcpy(final_T, guess, 16 * sizeof(float));  // icp.hpp:63
-  if (p->ransac_iterations <= 0) {
-    // no RANSAC step: the whole loop runs on the device (step -> reduce -> solve, back to back on one stream);
-    // the host only looks at the state every few iterations to stop enqueueing once a criterion has fired
-    // (iterations enqueued past that point are no-ops on the device)
-    int rc = pclmi_icp_set_criteria(c, p);
+  int rc = PCLMI_OK;
+  if (plane)
+    rc = pclmi_icp_set_point_to_plane(c, plane->tgt_normals, plane->n_tgt, plane->tn_stride, plane->src_normals, n_src,
+                                      plane->sn_stride);
+  if (!rc && p->ransac_iterations <= 0) {
+    // no RANSAC step: the whole loop runs on the device, ONE kernel per iteration (step, reduction, exchange with the
+    // other ranks, solve); the host only looks at the state every few iterations to stop enqueueing once a criterion
+    // has fired (iterations enqueued past that point are no-ops on the device).  Every rank enqueues the same chunks:
+    // the criteria see identical sums, so all ranks stop in the same iteration.
+    rc = pclmi_icp_set_criteria(c, p);
+    if (!rc && world > 1) rc = pclmi_icp_set_comm(c, comm);
     pclmi_icp_stats st;
     std::memset(&st, 0, sizeof(st));
+    set_identity(st.last_transform);
     int enqueued = 0;
+    const int chunk_max = world > 1 ? 16 : 8;
     while (!rc) {
-      const int chunk = std::max(1, std::min(8, p->max_iterations - enqueued));
+      const int chunk = std::max(1, std::min(chunk_max, p->max_iterations - enqueued));
       if ((rc = pclmi_icp_run_dev(c, p->max_correspondence_distance, chunk, nullptr))) break;
       enqueued += chunk;
       rc = pclmi_icp_state(c, final_T, &st);
@@ -797,14 +849,14 @@ int pclmi_icp_align(const pclmi_icp_params *p, const pclmi_tree *target, const f
   float T[16], Tprev[16];
   set_identity(T);
   RansacScratch rs;
-  int rc = PCLMI_OK, iters = 0, converged = 0;
-  double sums[PCLMI_ICP_NSUMS];
+  int iters = 0, converged = 0;
+  double sums[PCLMI_ICP_NSUMS_PLANE];
   double fit = 0.0, tdelta = 0.0;
   int64_t cnt = 0, used = 0;
-  while (!converged) {  // icp.hpp:72
+  while (!rc && !converged) {  // icp.hpp:72
     std::memcpy(Tprev, T, sizeof(T));
-    if ((rc = pclmi_icp_step(c, p->max_correspondence_distance, sums))) break;
-    cnt = (int64_t)std::llround(sums[0]);
+    if ((rc = icp_step_host(c, p->max_correspondence_distance, sums))) break;
+    cnt = (int64_t)std::llround(sums[c->i_pairs()]);
     if (cnt < p->min_correspondences) {  // icp.hpp:103-108
       set_error("not enough correspondences (%lld < %d): relax the threshold parameters", (long long)cnt,
                 p->min_correspondences);
@@ -813,8 +865,8 @@ int pclmi_icp_align(const pclmi_icp_params *p, const pclmi_tree *target, const f
     }
     used = cnt;
     const double *solve_sums = sums;
-    double rsums[PCLMI_ICP_NSUMS];
-    if (p->ransac_iterations > 0) {  // icp.hpp:113-150
+    double rsums[PCLMI_ICP_NSUMS_PLANE];
+    {  // icp.hpp:113-150
       int64_t ninl = -1;
       if ((rc = ransac_icp(c, rs, p, &ninl, rsums))) break;
       if (ninl >= 0) {
@@ -827,8 +879,8 @@ int pclmi_icp_align(const pclmi_icp_params *p, const pclmi_tree *target, const f
         break;
       }
     }
-    const double n_points = sums[18] > 0 ? sums[18] : (double)c->n;
-    if ((rc = solve_rigid_from_sums(solve_sums, T))) break;   // icp.hpp:171
+    const double n_points = sums[c->i_points()] > 0 ? sums[c->i_points()] : (double)c->n;
+    if ((rc = c->plane ? solve_point_to_plane(solve_sums, T) : solve_rigid_from_sums(solve_sums, T))) break;  // icp.hpp:171
     if ((rc = pclmi_icp_set_transform(c, T))) break;    // icp.hpp:174 (applied by the next step / end)
     mat4_mul_f32(T, final_T, final_T);                  // icp.hpp:177
     ++iters;
@@ -838,7 +890,7 @@ int pclmi_icp_align(const pclmi_icp_params *p, const pclmi_tree *target, const f
       for (int i = 0; i < 16; ++i) fs += std::fabs(T[i] - Tprev[i]);
       tdelta = fs;
     }
-    fit = sums[17] / n_points;  // registration.hpp:60-68
+    fit = sums[c->i_fit()] / n_points;  // registration.hpp:60-68
     if (iters >= p->max_iterations || tdelta < p->transformation_epsilon ||
         std::fabs(fit) <= p->euclidean_fitness_epsilon)  // icp.hpp:193-196
       converged = 1;
@@ -854,6 +906,30 @@ int pclmi_icp_align(const pclmi_icp_params *p, const pclmi_tree *target, const f
   }
   int rc2 = pclmi_icp_end(c, aligned);
   return rc ? rc : rc2;
+}
+
+}  // namespace
+
+int pclmi_icp_align(const pclmi_icp_params *p, const pclmi_tree *target, const float *src, size_t n_src,
+                    size_t stride_bytes, const float *guess, float final_T[16], float *aligned,
+                    pclmi_icp_stats *stats) {
+  return align_core(p, target, src, n_src, stride_bytes, guess, nullptr, nullptr, final_T, aligned, stats);
+}
+
+int pclmi_icp_align_sharded(const pclmi_icp_params *p, const pclmi_tree *target, const float *src, size_t n_src,
+                            size_t stride_bytes, const float *guess, pclmi_comm *comm, float final_T[16],
+                            float *aligned, pclmi_icp_stats *stats) {
+  PCLMI_CHECK(comm, PCLMI_ERR_INVALID, "NULL argument");
+  return align_core(p, target, src, n_src, stride_bytes, guess, comm, nullptr, final_T, aligned, stats);
+}
+
+int pclmi_icp_align_point_to_plane(const pclmi_icp_params *p, const pclmi_tree *target, const float *src, size_t n_src,
+                                   size_t stride_bytes, const float *src_normals, size_t sn_stride_bytes,
+                                   const float *tgt_normals, size_t n_tgt, size_t tn_stride_bytes, const float *guess,
+                                   pclmi_comm *comm, float final_T[16], float *aligned, pclmi_icp_stats *stats) {
+  PCLMI_CHECK(tgt_normals, PCLMI_ERR_INVALID, "tgt_normals is NULL");
+  const PlaneArgs pa{src_normals, sn_stride_bytes, tgt_normals, n_tgt, tn_stride_bytes};
+  return align_core(p, target, src, n_src, stride_bytes, guess, comm, &pa, final_T, aligned, stats);
 }
 
 // CorrespondenceRejectorSampleConsensus::getRemainingCorrespondences

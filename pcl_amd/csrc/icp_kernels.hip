@@ -128,7 +128,16 @@ __device__ __forceinline__ void wave_reduce_to_row(double (&v)[8], bool use, dou
 }
 
 constexpr int NS = PCLMI_ICP_NSUMS;  // 24
+constexpr int NSP = PCLMI_ICP_NSUMS_PLANE;  // 32: the point-to-plane loop (layout: pclmi.h)
 constexpr int ICP_WPB = 4;
+// EST: 0 = TransformationEstimationSVD, 1 = TransformationEstimationPointToPlaneLLS
+template <int EST>
+struct SumsOf {
+  static constexpr int n = EST ? NSP : NS;
+  static constexpr int pairs = EST ? 27 : 0;     // pairs under the distance threshold
+  static constexpr int fit_num = EST ? 29 : 17;  // sum (d_now - d_prev)
+  static constexpr int points = EST ? 30 : 18;   // points searched
+};
 
 // One lane turns the (all-reduced) sums into the next transform and evaluates the convergence criteria
 // (icp.hpp:103-108,171-196): the device-side twin of the loop body of pclmi_icp_align.
@@ -153,11 +162,12 @@ __device__ __forceinline__ void fetch_solve_in(const IcpDevState *__restrict__ s
 
 // One lane turns the (all-reduced) sums into the next transform and evaluates the convergence criteria
 // (icp.hpp:103-108,171-196): the device-side twin of the loop body of pclmi_icp_align.
+template <int EST>
 __device__ __forceinline__ void icp_solve_body(const double *__restrict__ sums, IcpDevState *__restrict__ st,
                                                double *work /* 42 doubles of LDS, rigid_solve.hpp svd3 */,
                                                const SolveIn *in) {
   const double *h = sums;
-  const long long cnt = llround(h[0]);
+  const long long cnt = llround(h[SumsOf<EST>::pairs]);
   st->last_pairs = (int)cnt;
   if (cnt < (long long)in->min_corr) {  // icp.hpp:103-108
     st->status = PCLMI_ERR_NOT_ENOUGH;
@@ -165,7 +175,7 @@ __device__ __forceinline__ void icp_solve_body(const double *__restrict__ sums, 
     return;
   }
   float Tprev[16], T[16], F[16];
-  if (!rs::solve_from_sums(h, T, work)) {
+  if (!(EST ? rs::solve_point_to_plane_sums(h, T, work) : rs::solve_from_sums(h, T, work))) {
     st->status = PCLMI_ERR_NOT_ENOUGH;
     st->done = 1;
     return;
@@ -185,8 +195,8 @@ __device__ __forceinline__ void icp_solve_body(const double *__restrict__ sums, 
   const int it = in->iterations + 1;
   st->iterations = it;
   const double tdelta = (double)rs::transform_delta(T, Tprev);
-  const double n_points = h[18] > 0 ? h[18] : 1.0;
-  const double fit = h[17] / n_points;  // registration.hpp:60-68
+  const double n_points = h[SumsOf<EST>::points] > 0 ? h[SumsOf<EST>::points] : 1.0;
+  const double fit = h[SumsOf<EST>::fit_num] / n_points;  // registration.hpp:60-68
   st->tdelta = tdelta;
   st->fit = fit;
   if (it >= in->max_iter || tdelta < in->teps || fabs(fit) <= in->feps) {  // icp.hpp:193-196
@@ -231,7 +241,10 @@ __device__ __forceinline__ double tail_column_sum(const double *col_base, int cn
 // workgroup happens to be last), exchanges them with the other ranks when a communicator is attached (comm_dev.hpp),
 // writes sums_out and, when asked, runs the solve.  Nobody waits for anybody inside the GPU: a workgroup that is not
 // last simply ends.  Returns to the caller only in the last workgroup's first wave... never: everything happens here.
-__device__ __forceinline__ void icp_step_tail(const IcpTail &tail, double *__restrict__ partials, double (*lds)[NS]) {
+template <int EST>
+__device__ __forceinline__ void icp_step_tail(const IcpTail &tail, double *__restrict__ partials,
+                                              double (*lds)[SumsOf<EST>::n]) {
+  constexpr int NS = SumsOf<EST>::n;  // shadows the SVD loop's count
   __shared__ int s_last;
   __shared__ double fin[NS];
   __shared__ double svd_work[42];
@@ -300,7 +313,7 @@ __device__ __forceinline__ void icp_step_tail(const IcpTail &tail, double *__res
         st->status = PCLMI_ERR_COMM;
         st->done = 1;
       } else if (tail.solve) {
-        icp_solve_body(fin, st, svd_work, &sin);
+        icp_solve_body<EST>(fin, st, svd_work, &sin);
       }
       st->ticks[3] = (unsigned long long)wall_clock64();
     }
@@ -311,16 +324,23 @@ __device__ __forceinline__ void icp_step_tail(const IcpTail &tail, double *__res
 // LANE: per-lane traversal (traverse.hpp lane_nearest) with `levels` rows of LDS per wave, started from the
 // distance to the previous step's neighbour (nn_slot, when have_prev) below the wave's common subtree;
 // !LANE: wave-uniform traversal (development switch PCLMI_NN1=union).
-template <bool LANE>
+// EST = 1 (TransformationEstimationPointToPlaneLLS, impl/transformation_estimation_point_to_plane_lls.hpp:141-245):
+// instead of the moments of the SVD estimator every pair adds its row of the linearised point-to-plane system to the
+// 21 + 6 sums of the 6x6 normal equations; tn_slot holds the target normals in bucket-slot order (next to the point a
+// lane has just found), src_skip (nullable) flags source points whose own normal is not finite (:158-174 skips them).
+template <bool LANE, int EST>
 __global__ __launch_bounds__(64 * ICP_WPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void icp_step_kernel(TreeView t, float4 *__restrict__ pts, int n,
                                                                  int apply, Xf T, float thr2f, double thr2,
                                                                  int *__restrict__ nn_idx, int *__restrict__ nn_slot,
                                                                  float *__restrict__ dist, double ox, double oy,
                                                                  double oz, double *__restrict__ partials,
                                                                  const IcpDevState *__restrict__ st, int levels,
-                                                                 int have_prev, IcpTail tail) {
+                                                                 int have_prev, IcpTail tail,
+                                                                 const float4 *__restrict__ tn_slot,
+                                                                 const unsigned char *__restrict__ src_skip) {
+  static_assert(LANE || !EST, "the point-to-plane loop reads the target normals by bucket slot");
   extern __shared__ float far_lds[];
-  __shared__ double lds[ICP_WPB][NS];
+  __shared__ double lds[ICP_WPB][SumsOf<EST>::n];
   if (st) {  // device-resident loop: the pending transform and the stop flag live in device memory
     if (st->done) return;
     apply = st->apply;
@@ -338,6 +358,8 @@ __global__ __launch_bounds__(64 * ICP_WPB) __attribute__((amdgpu_waves_per_eu(8,
   bool paired = false, counted = false;
   float4 p = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), 1.f);
   float4 q = p;
+  float4 m = p;  // EST: the target normal of the pair
+  bool contrib = false;
   float dc = 0.f, prev = 0.f;
   if (wave_live) {
     const bool alive = slot < n;
@@ -380,10 +402,43 @@ __global__ __launch_bounds__(64 * ICP_WPB) __attribute__((amdgpu_waves_per_eu(8,
         if ((double)d < thr2) {  // strict, icp.hpp:93
           q = LANE ? rows[bslot] : reinterpret_cast<const float4 *>(t.cloud)[idx];
           paired = true;
+          if (EST) {
+            m = tn_slot[bslot];
+            contrib = finite3(m) && !(src_skip && src_skip[slot]);
+          }
         }
       }
     }
   }
+  if constexpr (EST != 0) {
+    // fp32 expressions widened on assignment, as the reference writes them (:186-188, :219)
+    const double a = (double)__fsub_rn(__fmul_rn(m.z, p.y), __fmul_rn(m.y, p.z));
+    const double b = (double)__fsub_rn(__fmul_rn(m.x, p.z), __fmul_rn(m.z, p.x));
+    const double c = (double)__fsub_rn(__fmul_rn(m.y, p.x), __fmul_rn(m.x, p.y));
+    const double nx = m.x, ny = m.y, nz = m.z;
+    float df = __fadd_rn(__fadd_rn(__fmul_rn(m.x, q.x), __fmul_rn(m.y, q.y)), __fmul_rn(m.z, q.z));
+    df = __fsub_rn(__fsub_rn(__fsub_rn(df, __fmul_rn(m.x, p.x)), __fmul_rn(m.y, p.y)), __fmul_rn(m.z, p.z));
+    const double dd = df;
+    {
+      double v[8] = {a * a, a * b, a * c, a * nx, a * ny, a * nz, b * b, b * c};
+      wave_reduce_to_row(v, contrib, &lds[wib][0], lane);
+    }
+    {
+      double v[8] = {b * nx, b * ny, b * nz, c * c, c * nx, c * ny, c * nz, nx * nx};
+      wave_reduce_to_row(v, contrib, &lds[wib][8], lane);
+    }
+    {
+      double v[8] = {nx * ny, nx * nz, ny * ny, ny * nz, nz * nz, a * dd, b * dd, c * dd};
+      wave_reduce_to_row(v, contrib, &lds[wib][16], lane);
+    }
+    {
+      double v[8] = {contrib ? nx * dd : 0.0, contrib ? ny * dd : 0.0, contrib ? nz * dd : 0.0, paired ? 1.0 : 0.0,
+                     (double)dc,              (double)dc - (double)prev,  1.0,                      0.0};
+      wave_reduce_to_row(v, counted, &lds[wib][24], lane);
+    }
+    __syncthreads();
+    icp_step_tail<1>(tail, partials, lds);
+  } else {
   // fp64 moments, reduced in three groups of eight so that at most 16 accumulator registers are live at a
   // time (the register budget is 64 VGPRs = 8 waves per SIMD: the search is latency-bound)
   const double sx = (double)p.x - ox, sy = (double)p.y - oy, sz = (double)p.z - oz;
@@ -402,7 +457,8 @@ __global__ __launch_bounds__(64 * ICP_WPB) __attribute__((amdgpu_waves_per_eu(8,
     wave_reduce_to_row(v, counted, &lds[wib][16], lane);
   }
   __syncthreads();
-  icp_step_tail(tail, partials, lds);
+  icp_step_tail<0>(tail, partials, lds);
+  }
 }
 
 // fixed-order sum of one column of block partials by one workgroup of 256: element r of column j sits at
@@ -430,6 +486,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double *__re
   if (threadIdx.x == 0) out[j] = s;
 }
 
+template <int EST>
 __global__ __launch_bounds__(64) void icp_solve_kernel(const double *__restrict__ sums, IcpDevState *__restrict__ st) {
   __shared__ double work[42];
   __shared__ SolveIn in;
@@ -437,7 +494,7 @@ __global__ __launch_bounds__(64) void icp_solve_kernel(const double *__restrict_
   fetch_solve_in(st, &in, threadIdx.x);
   __syncthreads();
   if (threadIdx.x != 0) return;
-  icp_solve_body(sums, st, work, &in);
+  icp_solve_body<EST>(sums, st, work, &in);
 }
 
 __global__ void transform_pending_kernel(float4 *__restrict__ pts, int n, const IcpDevState *__restrict__ st) {
@@ -484,6 +541,55 @@ __global__ __launch_bounds__(64 * PR_WPB) void pair_reduce_kernel(const float4 *
     acc[19] += ox; acc[20] += oy; acc[21] += oz;
   }
   block_reduce_store<NS, PR_WPB>(acc, lds, lane, wib, partials + (size_t)blockIdx.x * NS);
+}
+
+// the 21 + 6 sums of the point-to-plane normal equations over explicitly paired points (the RANSAC inlier refit of the
+// point-to-plane loop): src by slot, tgt and its normals by cloud row; layout as the step kernel's (pclmi.h)
+__global__ __launch_bounds__(64 * PR_WPB) void pair_reduce_plane_kernel(const float4 *__restrict__ src,
+                                                                         const int *__restrict__ sidx,
+                                                                         const float4 *__restrict__ tgt,
+                                                                         const int *__restrict__ tidx,
+                                                                         const float4 *__restrict__ tn,
+                                                                         const unsigned char *__restrict__ src_skip,
+                                                                         const unsigned char *__restrict__ flags, int n,
+                                                                         double *__restrict__ partials) {
+  __shared__ double lds[PR_WPB][NSP];
+  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  double acc[NSP];
+#pragma unroll
+  for (int j = 0; j < NSP; ++j) acc[j] = 0.0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    if (flags && !flags[i]) continue;
+    const int si = sidx ? sidx[i] : i, ti = tidx ? tidx[i] : i;
+    acc[27] += 1.0;
+    const float4 p = src[si], q = tgt[ti], m = tn[ti];
+    if (!finite3(p) || !finite3(q) || !finite3(m) || (src_skip && src_skip[si])) continue;
+    const double a = (double)__fsub_rn(__fmul_rn(m.z, p.y), __fmul_rn(m.y, p.z));
+    const double b = (double)__fsub_rn(__fmul_rn(m.x, p.z), __fmul_rn(m.z, p.x));
+    const double c = (double)__fsub_rn(__fmul_rn(m.y, p.x), __fmul_rn(m.x, p.y));
+    float df = __fadd_rn(__fadd_rn(__fmul_rn(m.x, q.x), __fmul_rn(m.y, q.y)), __fmul_rn(m.z, q.z));
+    df = __fsub_rn(__fsub_rn(__fsub_rn(df, __fmul_rn(m.x, p.x)), __fmul_rn(m.y, p.y)), __fmul_rn(m.z, p.z));
+    const double v[6] = {a, b, c, (double)m.x, (double)m.y, (double)m.z};
+    const double dd = df;
+    int o = 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int k = r; k < 6; ++k) acc[o++] += v[r] * v[k];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) acc[21 + r] += v[r] * dd;
+  }
+  block_reduce_store<NSP, PR_WPB>(acc, lds, lane, wib, partials + (size_t)blockIdx.x * NSP);
+}
+
+// target normals (cloud rows) -> bucket-slot order: the row a lane's search ends at sits next to its normal
+__global__ void normals_to_slots_kernel(const float4 *__restrict__ slot_rows, int nslots,
+                                        const float4 *__restrict__ tn_rows, float4 *__restrict__ tn_slot) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nslots) return;
+  const int idx = __float_as_int(slot_rows[j].w);
+  const float nanv = __builtin_nanf("");
+  tn_slot[j] = idx >= 0 ? tn_rows[idx] : make_float4(nanv, nanv, nanv, 0.f);
 }
 
 // the same sums over a correspondence list with the clouds in their caller layout (strided rows):
@@ -642,8 +748,9 @@ void launch_transform_pending(float4 *d_pts, size_t n, IcpDevState *st, hipStrea
   hipLaunchKernelGGL(clear_apply_kernel, dim3(1), dim3(1), 0, s, st);
 }
 
-void launch_icp_solve(const double *d_sums, IcpDevState *st, hipStream_t s) {
-  hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(64), 0, s, d_sums, st);
+void launch_icp_solve(const double *d_sums, IcpDevState *st, hipStream_t s, bool plane) {
+  if (plane) hipLaunchKernelGGL(icp_solve_kernel<1>, dim3(1), dim3(64), 0, s, d_sums, st);
+  else hipLaunchKernelGGL(icp_solve_kernel<0>, dim3(1), dim3(64), 0, s, d_sums, st);
 }
 
 void launch_pack(const float *d_in, size_t stride_f, const int *d_rows, size_t n, float4 *d_out, hipStream_t s) {
@@ -671,19 +778,28 @@ unsigned icp_step_groups(size_t n) { return (icp_step_blocks(n) + ICP_GROUP - 1)
 
 void launch_icp_step(const pclmi_tree *t, float4 *d_pts, size_t n, bool apply, const Xf &T, double thr2,
                      int *d_nn, int *d_nn_slot, float *d_dist, const double origin[3], double *d_partials,
-                     hipStream_t s, IcpDevState *st, bool have_prev, const IcpTail &tail) {
+                     hipStream_t s, IcpDevState *st, bool have_prev, const IcpTail &tail, const float4 *d_tn_slot,
+                     const unsigned char *d_src_skip) {
   const unsigned blocks = icp_step_blocks(n);
-  const int levels = nn1_per_lane() ? lane_nearest_levels(t->M) : 0;
+  const bool plane = d_tn_slot != nullptr;  // the point-to-plane loop always walks per lane
+  const int levels = (plane || nn1_per_lane()) ? lane_nearest_levels(t->M) : 0;
   TimingScope ts(PCLMI_TIMER_ICP_STEP, s);
-  if (levels > 0)
-    hipLaunchKernelGGL((icp_step_kernel<true>), dim3(blocks), dim3(64 * ICP_WPB),
-                       (size_t)ICP_WPB * levels * 64 * sizeof(float), s, t->view(), d_pts, (int)n, apply ? 1 : 0, T,
-                       (float)thr2, thr2, d_nn, d_nn_slot, d_dist, origin[0], origin[1], origin[2], d_partials,
-                       (const IcpDevState *)st, levels, have_prev ? 1 : 0, tail);
+  const size_t lds_bytes = (size_t)ICP_WPB * levels * 64 * sizeof(float);
+  if (plane)
+    hipLaunchKernelGGL((icp_step_kernel<true, 1>), dim3(blocks), dim3(64 * ICP_WPB), lds_bytes, s, t->view(), d_pts,
+                       (int)n, apply ? 1 : 0, T, (float)thr2, thr2, d_nn, d_nn_slot, d_dist, origin[0], origin[1],
+                       origin[2], d_partials, (const IcpDevState *)st, levels, have_prev ? 1 : 0, tail, d_tn_slot,
+                       d_src_skip);
+  else if (levels > 0)
+    hipLaunchKernelGGL((icp_step_kernel<true, 0>), dim3(blocks), dim3(64 * ICP_WPB), lds_bytes, s, t->view(), d_pts,
+                       (int)n, apply ? 1 : 0, T, (float)thr2, thr2, d_nn, d_nn_slot, d_dist, origin[0], origin[1],
+                       origin[2], d_partials, (const IcpDevState *)st, levels, have_prev ? 1 : 0, tail,
+                       (const float4 *)nullptr, (const unsigned char *)nullptr);
   else
-    hipLaunchKernelGGL((icp_step_kernel<false>), dim3(blocks), dim3(64 * ICP_WPB), 0, s, t->view(), d_pts, (int)n,
+    hipLaunchKernelGGL((icp_step_kernel<false, 0>), dim3(blocks), dim3(64 * ICP_WPB), 0, s, t->view(), d_pts, (int)n,
                        apply ? 1 : 0, T, (float)thr2, thr2, d_nn, d_nn_slot, d_dist, origin[0], origin[1], origin[2],
-                       d_partials, (const IcpDevState *)st, 0, 0, tail);
+                       d_partials, (const IcpDevState *)st, 0, 0, tail, (const float4 *)nullptr,
+                       (const unsigned char *)nullptr);
 }
 
 unsigned pair_reduce_blocks(size_t n) {
@@ -699,6 +815,23 @@ void launch_pair_reduce(const float4 *src, const int *sidx, const float4 *tgt, c
                      origin[0], origin[1], origin[2], d_partials);
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(NS), dim3(256), 0, s, d_partials, (int)blocks, (size_t)NS, (size_t)1,
                      d_sums);
+}
+
+void launch_pair_reduce_plane(const float4 *src, const int *sidx, const float4 *tgt, const int *tidx, const float4 *tn,
+                              const unsigned char *src_skip, const unsigned char *flags, size_t n, double *d_partials,
+                              double *d_sums, hipStream_t s) {
+  const unsigned blocks = pair_reduce_blocks(n);
+  hipLaunchKernelGGL(pair_reduce_plane_kernel, dim3(blocks), dim3(64 * PR_WPB), 0, s, src, sidx, tgt, tidx, tn, src_skip,
+                     flags, (int)n, d_partials);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(NSP), dim3(256), 0, s, d_partials, (int)blocks, (size_t)NSP, (size_t)1,
+                     d_sums);
+}
+
+void launch_normals_to_slots(const pclmi_tree *t, const float4 *tn_rows, float4 *tn_slot, hipStream_t s) {
+  const size_t nslots = (size_t)t->M * kLeafSize;
+  if (nslots)
+    hipLaunchKernelGGL(normals_to_slots_kernel, dim3(blocks_for(nslots, 256)), dim3(256), 0, s,
+                       reinterpret_cast<const float4 *>(t->d_slot), (int)nslots, tn_rows, tn_slot);
 }
 
 void launch_corr_reduce(const float *src, size_t src_stride_f, const float *tgt, size_t tgt_stride_f,

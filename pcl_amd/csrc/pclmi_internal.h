@@ -251,10 +251,10 @@ struct IcpDevState {
 // What the workgroup that finishes a step's reduction goes on to do (icp_kernels.hip icp_step_tail): group sums,
 // the launch's sums, the exchange with the other ranks (comm.world > 1), the solve (solve != 0, needs st).
 struct IcpTail {
-  double *gpart = nullptr;          // [PCLMI_ICP_NSUMS][ngroups] group sums
+  double *gpart = nullptr;          // [sums][ngroups] group sums
   unsigned int *gticket = nullptr;  // [ngroups] arrival tickets, zero between launches
   unsigned int *ticket = nullptr;   // groups finished, zero between launches
-  double *sums_out = nullptr;       // [PCLMI_ICP_NSUMS] the launch's (all-reduced) sums
+  double *sums_out = nullptr;       // [PCLMI_ICP_NSUMS or _PLANE] the launch's (all-reduced) sums
   IcpDevState *st = nullptr;
   int solve = 0;
   int ngroups = 1;
@@ -264,7 +264,7 @@ CommView comm_view(const pclmi_comm *c);
 int comm_device(const pclmi_comm *c);
 void launch_transform(float4 *d_pts, size_t n, const Xf &T, hipStream_t s);
 void launch_transform_pending(float4 *d_pts, size_t n, IcpDevState *st, hipStream_t s);  // applies st->T iff st->apply
-void launch_icp_solve(const double *d_sums, IcpDevState *st, hipStream_t s);
+void launch_icp_solve(const double *d_sums, IcpDevState *st, hipStream_t s, bool plane = false);
 void launch_pack(const float *d_in, size_t stride_f, const int *d_rows, size_t n, float4 *d_out, hipStream_t s);
 void launch_permute(const float4 *in, const int *order, size_t n, float4 *out, hipStream_t s);
 void launch_unpermute(const float4 *in, const int *order, size_t n, float4 *out, hipStream_t s);
@@ -274,7 +274,13 @@ unsigned icp_step_groups(size_t n);
 // workgroup that arrives last carries out `tail` (sums, exchange, solve).
 void launch_icp_step(const pclmi_tree *t, float4 *d_pts, size_t n, bool apply, const Xf &T, double thr2,
                      int *d_nn, int *d_nn_slot, float *d_dist, const double origin[3], double *d_partials,
-                     hipStream_t s, IcpDevState *st, bool have_prev, const IcpTail &tail);
+                     hipStream_t s, IcpDevState *st, bool have_prev, const IcpTail &tail,
+                     const float4 *d_tn_slot = nullptr, const unsigned char *d_src_skip = nullptr);
+// point-to-plane loop (d_tn_slot != nullptr above): PCLMI_ICP_NSUMS_PLANE sums per launch
+void launch_pair_reduce_plane(const float4 *src, const int *sidx, const float4 *tgt, const int *tidx, const float4 *tn,
+                              const unsigned char *src_skip, const unsigned char *flags, size_t n, double *d_partials,
+                              double *d_sums, hipStream_t s);
+void launch_normals_to_slots(const pclmi_tree *t, const float4 *tn_rows, float4 *tn_slot, hipStream_t s);
 // development switch (environment PCLMI_NN1=union): 1-NN searches use the wave-uniform traversal instead of
 // the per-lane one
 bool nn1_per_lane();

@@ -33,48 +33,14 @@ int solve_rigid_from_sums(const double sums[PCLMI_ICP_NSUMS], float T[16]) {
 
 void mat4_mul_f32(const float A[16], const float B[16], float C[16]) { rs::mat4_mul(A, B, C); }
 
-// TransformationEstimationPointToPlaneLLS: x = ATA^-1 ATb (Gauss-Jordan with partial pivoting in fp64, standing in
-// for Eigen's ATA.inverse () * ATb) and constructTransformationMatrix
-// (registration/include/pcl/registration/impl/transformation_estimation_point_to_plane_lls.hpp:118-139,230-245).
-// sums: the 21 upper-triangle entries of ATA row by row, then the 6 of ATb.
+// TransformationEstimationPointToPlaneLLS: the 6x6 solve and constructTransformationMatrix live in rigid_solve.hpp
+// (shared with the device loop).  sums: the 21 upper-triangle entries of ATA row by row, then the 6 of ATb.
 int solve_point_to_plane(const double sums[27], float T[16]) {
-  for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.f : 0.f;
-  double M[6][7];
-  int o = 0;
-  for (int r = 0; r < 6; ++r)
-    for (int c = r; c < 6; ++c) M[r][c] = M[c][r] = sums[o++];
-  for (int r = 0; r < 6; ++r) M[r][6] = sums[21 + r];
-  for (int c = 0; c < 6; ++c) {
-    int piv = c;
-    for (int r = c + 1; r < 6; ++r)
-      if (std::fabs(M[r][c]) > std::fabs(M[piv][c])) piv = r;
-    if (M[piv][c] == 0.0 || !std::isfinite(M[piv][c])) {
-      set_error("point-to-plane estimation: the 6x6 normal equations are singular (degenerate geometry)");
-      return PCLMI_ERR_NOT_ENOUGH;
-    }
-    if (piv != c)
-      for (int k = 0; k < 7; ++k) std::swap(M[c][k], M[piv][k]);
-    for (int r = 0; r < 6; ++r) {
-      if (r == c) continue;
-      const double f = M[r][c] / M[c][c];
-      for (int k = c; k < 7; ++k) M[r][k] -= f * M[c][k];
-    }
+  double work[42];
+  if (!rs::solve_point_to_plane_sums(sums, T, work)) {
+    set_error("point-to-plane estimation: the 6x6 normal equations are singular (degenerate geometry)");
+    return PCLMI_ERR_NOT_ENOUGH;
   }
-  double x[6];
-  for (int r = 0; r < 6; ++r) x[r] = M[r][6] / M[r][r];
-  const double al = x[0], be = x[1], ga = x[2];
-  T[0] = (float)(std::cos(ga) * std::cos(be));
-  T[1] = -(float)(std::sin(ga) * std::cos(al) + std::cos(ga) * std::sin(be) * std::sin(al));
-  T[2] = (float)(std::sin(ga) * std::sin(al) + std::cos(ga) * std::sin(be) * std::cos(al));
-  T[4] = (float)(std::sin(ga) * std::cos(be));
-  T[5] = (float)(std::cos(ga) * std::cos(al) + std::sin(ga) * std::sin(be) * std::sin(al));
-  T[6] = -(float)(std::cos(ga) * std::sin(al) + std::sin(ga) * std::sin(be) * std::cos(al));
-  T[8] = -(float)(std::sin(be));
-  T[9] = (float)(std::cos(be) * std::sin(al));
-  T[10] = (float)(std::cos(be) * std::cos(al));
-  T[3] = (float)x[3];
-  T[7] = (float)x[4];
-  T[11] = (float)x[5];
   return PCLMI_OK;
 }
 

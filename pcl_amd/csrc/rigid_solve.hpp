@@ -251,6 +251,99 @@ PCLMI_HD bool solve_from_sums(const double *sums, float T[16], double *work /* 4
   return true;
 }
 
+// sin and cos of x from IEEE +,-,* and floor only (host and device give the same bits; the device maths library's
+// fp64 sin / cos would also pull a large argument-reduction routine into the ICP step kernel).  Cody-Waite reduction
+// by pi/2 in two pieces, then the Taylor series on [-pi/4, pi/4] up to x^19 / x^18 (truncation < 3e-18): accurate to
+// ~1e-16 for |x| < 1e5, far inside the fp32 rounding the results go through.
+PCLMI_HD void sincos_small(double x, double *s_out, double *c_out) {
+  if (!(fabs(x) <= 1e9)) {  // non-finite or absurd angle (singular geometry): NaN, as garbage in gives garbage out
+    *s_out = *c_out = (x - x) / (x - x);
+    return;
+  }
+  const double k = floor(x * 0.63661977236758134308 + 0.5);
+  const double r = (x - k * 1.57079632679489655800e+00) - k * 6.12323399573676603587e-17;
+  const double z = r * r;
+  double s = -8.22063524662432971696e-18;  // -1/19!
+  s = s * z + 2.81145725434552076320e-15;  // 1/17!
+  s = s * z - 7.64716373181981647590e-13;  // -1/15!
+  s = s * z + 1.60590438368216145994e-10;  // 1/13!
+  s = s * z - 2.50521083854417187751e-08;  // -1/11!
+  s = s * z + 2.75573192239858906526e-06;  // 1/9!
+  s = s * z - 1.98412698412698412698e-04;  // -1/7!
+  s = s * z + 8.33333333333333333333e-03;  // 1/5!
+  s = s * z - 1.66666666666666666667e-01;  // -1/3!
+  s = r + r * (z * s);
+  double c = 1.56192069685862264622e-16;   // 1/18!
+  c = c * z - 4.77947733238738529744e-14;  // -1/16!
+  c = c * z + 1.14707455977297247139e-11;  // 1/14!
+  c = c * z - 2.08767569878680989792e-09;  // -1/12!
+  c = c * z + 2.75573192239858906526e-07;  // 1/10!
+  c = c * z - 2.48015873015873015873e-05;  // -1/8!
+  c = c * z + 1.38888888888888888889e-03;  // 1/6!
+  c = c * z - 4.16666666666666666667e-02;  // -1/4!
+  c = c * z + 0.5;
+  c = 1.0 - z * c;
+  const long long q = (long long)k & 3;  // quadrant
+  const double ss = (q & 1) ? c : s, cc = (q & 1) ? s : c;
+  *s_out = (q & 2) ? -ss : ss;
+  *c_out = (q == 1 || q == 2) ? -cc : cc;
+}
+
+// TransformationEstimationPointToPlaneLLS: x = ATA^-1 ATb (Gauss-Jordan with partial pivoting in fp64, standing in
+// for Eigen's ATA.inverse () * ATb) and constructTransformationMatrix
+// (registration/include/pcl/registration/impl/transformation_estimation_point_to_plane_lls.hpp:118-139,230-245).
+// sums: the 21 upper-triangle entries of ATA row by row, then the 6 of ATb.  work: 42 doubles (the augmented 6x7
+// system; LDS on the GPU: the elimination indexes it with run-time indices).  Returns false (T = identity) when the
+// normal equations are singular.
+PCLMI_HD bool solve_point_to_plane_sums(const double *sums, float T[16], double *work) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.f : 0.f;
+  double *M = work;  // [6][7]
+  int o = 0;
+  for (int r = 0; r < 6; ++r)
+    for (int c = r; c < 6; ++c) {
+      const double v = sums[o++];
+      M[r * 7 + c] = v;
+      M[c * 7 + r] = v;
+    }
+  for (int r = 0; r < 6; ++r) M[r * 7 + 6] = sums[21 + r];
+  for (int c = 0; c < 6; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < 6; ++r)
+      if (fabs(M[r * 7 + c]) > fabs(M[piv * 7 + c])) piv = r;
+    const double d = M[piv * 7 + c];
+    if (d == 0.0 || !(fabs(d) <= 1.7976931348623157e308)) return false;
+    if (piv != c)
+      for (int k = 0; k < 7; ++k) {
+        const double t = M[c * 7 + k];
+        M[c * 7 + k] = M[piv * 7 + k];
+        M[piv * 7 + k] = t;
+      }
+    for (int r = 0; r < 6; ++r) {
+      if (r == c) continue;
+      const double f = M[r * 7 + c] / M[c * 7 + c];
+      for (int k = c; k < 7; ++k) M[r * 7 + k] -= f * M[c * 7 + k];
+    }
+  }
+  double sa, ca, sb, cb, sg, cg;
+  sincos_small(M[0 * 7 + 6] / M[0 * 7 + 0], &sa, &ca);  // alpha
+  sincos_small(M[1 * 7 + 6] / M[1 * 7 + 1], &sb, &cb);  // beta
+  sincos_small(M[2 * 7 + 6] / M[2 * 7 + 2], &sg, &cg);  // gamma
+  T[0] = (float)(cg * cb);
+  T[1] = -(float)(sg * ca + cg * sb * sa);
+  T[2] = (float)(sg * sa + cg * sb * ca);
+  T[4] = (float)(sg * cb);
+  T[5] = (float)(cg * ca + sg * sb * sa);
+  T[6] = -(float)(cg * sa + sg * sb * ca);
+  T[8] = -(float)(sb);
+  T[9] = (float)(cb * sa);
+  T[10] = (float)(cb * ca);
+  T[3] = (float)(M[3 * 7 + 6] / M[3 * 7 + 3]);
+  T[7] = (float)(M[4 * 7 + 6] / M[4 * 7 + 4]);
+  T[11] = (float)(M[5 * 7 + 6] / M[5 * 7 + 5]);
+  return true;
+}
+
 // C = A * B (row-major 4x4, fp32, k ascending); C may alias A or B
 PCLMI_HD void mat4_mul(const float A[16], const float B[16], float C[16]) {
   float R[16];

@@ -22,6 +22,12 @@ def clouds():
     return tgt, src
 
 
+def target_normals(tgt):
+    """Analytic unit normals of the surface clouds() samples."""
+    n = np.stack([-0.6 * np.cos(tgt[:, 0] * 0.2), 0.3 * np.sin(tgt[:, 1] * 0.15), np.ones(len(tgt))], axis=1)
+    return (n / np.linalg.norm(n, axis=1, keepdims=True)).astype(np.float32)
+
+
 def main():
     rank, world, name, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
     import torch
@@ -76,7 +82,9 @@ def main():
     comm.status()
     # the one-call form: every rank passes the whole source, the library cuts the Hilbert-ordered run of this rank
     rc3, T3, al3, st3 = capi.icp_align_sharded(tree, src, comm, p)
-    np.savez(out, rc3=rc3, T3=T3, al3=al3, it3=st3.iterations, pairs3=st3.last_correspondences, rc=rc, T=T, iterations=st.iterations, converged=st.converged, pairs=st.last_correspondences,
+    # the same with TransformationEstimationPointToPlaneLLS: 32 sums per exchange, 6x6 solve in the last workgroup
+    rc4, T4, al4, st4 = capi.icp_align_point_to_plane(tree, src, target_normals(tgt), p, comm=comm)
+    np.savez(out, rc4=rc4, T4=T4, al4=al4, it4=st4.iterations, pairs4=st4.last_correspondences, rc3=rc3, T3=T3, al3=al3, it3=st3.iterations, pairs3=st3.last_correspondences, rc=rc, T=T, iterations=st.iterations, converged=st.converged, pairs=st.last_correspondences,
              aligned=aligned, rc2=rc2, T2=T2, it2=st2.iterations, pairs2=st2.last_correspondences)
     comm.close()
 

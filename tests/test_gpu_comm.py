@@ -68,3 +68,11 @@ def test_two_process_allreduce_and_sharded_icp(tmp_path):
     assert (own_a ^ own_b).all() and abs(int(own_a.sum()) - int(own_b.sum())) <= 1, "every row belongs to one rank"
     merged = np.where(own_a[:, None], a["al3"], b["al3"])
     assert np.abs(merged[:, :3] - out[:, :3]).max() <= 1e-4
+    # point-to-plane estimator over two ranks == one process (32 sums exchanged, 6x6 solve on every rank)
+    assert int(a["rc4"]) == 0 and np.array_equal(a["T4"], b["T4"]) and int(a["it4"]) == int(b["it4"])
+    rc, T, out, st = capi.icp_align_point_to_plane(tree, src, comm_worker.target_normals(tgt), p)
+    assert rc == 0 and int(a["it4"]) == st.iterations and int(a["pairs4"]) == st.last_correspondences
+    assert np.abs(a["T4"] - T).max() <= 1e-5
+    own_a = ~np.isnan(a["al4"][:, 0])
+    merged = np.where(own_a[:, None], a["al4"], b["al4"])
+    assert np.abs(merged[:, :3] - out[:, :3]).max() <= 1e-4
