@@ -3,6 +3,9 @@
 // The whole correspondence loop - 1-NN, threshold, optional RANSAC rejection, centroid /
 // cross-covariance reduction, SVD, transform, convergence tests - runs in ONE library call
 // (pclmi_icp_align); the source cloud crosses PCIe once in, once out.
+// setTransformationEstimation (registration.h:140-160) selects the estimator of icp.hpp:171:
+// TransformationEstimationSVD (default) or TransformationEstimationPointToPlaneLLS - then the loop is
+// pclmi_icp_align_point_to_plane and the point types must carry normal_x/y/z (e.g. pcl::PointNormal).
 #ifndef PCLMI_FACADE_REGISTRATION_ICP_H_
 #define PCLMI_FACADE_REGISTRATION_ICP_H_
 
@@ -13,6 +16,14 @@
 #include <pcl/registration/transformation_estimation_svd.h>
 
 namespace pcl {
+
+namespace detail {
+// &p.normal_x when the point type has normals, nullptr otherwise
+template <typename P>
+auto normal_ptr_of(const P *p, int) -> decltype(&p->normal_x) { return &p->normal_x; }
+template <typename P>
+const float *normal_ptr_of(const P *, long) { return nullptr; }
+}  // namespace detail
 
 template <typename PointSource, typename PointTarget>
 class IterativeClosestPoint : public Registration<PointSource, PointTarget> {
@@ -41,7 +52,6 @@ class IterativeClosestPoint : public Registration<PointSource, PointTarget> {
     reg_name_ = "IterativeClosestPoint";
     ransac_iterations_ = 1000;
     transformation_estimation_.reset(new pcl::registration::TransformationEstimationSVD<PointSource, PointTarget>);
-    svd_estimation_ = transformation_estimation_.get();
   }
 
   /** \brief Not in the reference: run align() over the ranks of a pclmi_comm (one process per GPU, every process
@@ -59,12 +69,20 @@ class IterativeClosestPoint : public Registration<PointSource, PointTarget> {
   void computeTransformation(PointCloudSource &output, const Matrix4f &guess) override {
     nr_iterations_ = 0;
     std::memset(&stats_, 0, sizeof(stats_));
-    if (transformation_estimation_.get() != svd_estimation_) {
-      PCL_ERROR("[pcl::%s::computeTransformation] only TransformationEstimationSVD is supported by the device loop\n",
-                getClassName().c_str());
+    const int loop = transformation_estimation_ ? transformation_estimation_->deviceLoop() : -1;
+    if (loop < 0) {
+      PCL_ERROR("[pcl::%s::computeTransformation] the device loop runs TransformationEstimationSVD or "
+                "TransformationEstimationPointToPlaneLLS; this estimator has no device loop\n", getClassName().c_str());
       return;
     }
     if (!tree_->getDeviceTree() || output.points.empty()) return;
+    const float *src_normals = detail::normal_ptr_of(output.points.data(), 0);
+    const float *tgt_normals = Base::target_ ? detail::normal_ptr_of(Base::target_->points.data(), 0) : nullptr;
+    if (loop == 1 && !tgt_normals) {
+      PCL_ERROR("[pcl::%s::computeTransformation] TransformationEstimationPointToPlaneLLS needs a target point type "
+                "with normals (normal_x, normal_y, normal_z)\n", getClassName().c_str());
+      return;
+    }
     if (Base::point_representation_ && !Base::point_representation_->isTrivial())
       PCL_WARN("[pcl::%s::computeTransformation] the point representation applies to the target tree only: the "
                "correspondence loop reads the source's raw x, y, z\n", getClassName().c_str());
@@ -85,7 +103,12 @@ class IterativeClosestPoint : public Registration<PointSource, PointTarget> {
       for (size_t i = 0; i < aligned.size(); ++i) aligned[i] = std::numeric_limits<float>::quiet_NaN();
     const float *src_xyz = reinterpret_cast<const float *>(output.points.data());
     const int rc =
-        sharded ? pclmi_icp_align_sharded(&p, tree_->getDeviceTree(), src_xyz, output.points.size(), sizeof(PointSource),
+        loop == 1 ? pclmi_icp_align_point_to_plane(&p, tree_->getDeviceTree(), src_xyz, output.points.size(),
+                                                   sizeof(PointSource), src_normals, sizeof(PointSource), tgt_normals,
+                                                   Base::target_->points.size(), sizeof(PointTarget),
+                                                   guess.isIdentity() ? nullptr : guess.data(), comm_,
+                                                   final_transformation_.data(), aligned.data(), &stats_)
+        : sharded ? pclmi_icp_align_sharded(&p, tree_->getDeviceTree(), src_xyz, output.points.size(), sizeof(PointSource),
                                           guess.isIdentity() ? nullptr : guess.data(), comm_,
                                           final_transformation_.data(), aligned.data(), &stats_)
                 : pclmi_icp_align(&p, tree_->getDeviceTree(), src_xyz, output.points.size(), sizeof(PointSource),
@@ -128,7 +151,6 @@ class IterativeClosestPoint : public Registration<PointSource, PointTarget> {
               stats_.fitness_delta);
   }
 
-  const void *svd_estimation_;
   pclmi_icp_stats stats_;
   pclmi_comm *comm_ = nullptr;
 };

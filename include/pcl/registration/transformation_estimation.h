@@ -25,6 +25,11 @@ class TransformationEstimation {
   TransformationEstimation() {}
   virtual ~TransformationEstimation() {}
 
+  /** \brief Not in the reference: which fused device loop IterativeClosestPoint runs for this estimator
+    * (0: the SVD loop, 1: the point-to-plane loop of pclmi_icp_align_point_to_plane, -1: none - align() reports an
+    * error: the per-iteration estimator call of icp.hpp:171 does not leave the device). */
+  virtual int deviceLoop() const { return -1; }
+
   virtual void estimateRigidTransformation(const pcl::PointCloud<PointSource> &cloud_src,
                                            const pcl::PointCloud<PointTarget> &cloud_tgt,
                                            Matrix4 &transformation_matrix) const = 0;

@@ -21,6 +21,7 @@ class TransformationEstimationPointToPlaneLLS : public TransformationEstimation<
 
   TransformationEstimationPointToPlaneLLS() {}
   virtual ~TransformationEstimationPointToPlaneLLS() {}
+  int deviceLoop() const override { return 1; }
 
   void estimateRigidTransformation(const pcl::PointCloud<PointSource> &cloud_src,
                                    const pcl::PointCloud<PointTarget> &cloud_tgt,

@@ -20,6 +20,7 @@ class TransformationEstimationSVD : public TransformationEstimation<PointSource,
 
   TransformationEstimationSVD() {}
   virtual ~TransformationEstimationSVD() {}
+  int deviceLoop() const override { return 0; }
 
   void estimateRigidTransformation(const pcl::PointCloud<PointSource> &cloud_src,
                                    const pcl::PointCloud<PointTarget> &cloud_tgt,

@@ -12,6 +12,7 @@
 #include <sstream>
 #include <string>
 
+#include <pcl/common/io.h>
 #include <pcl/common/time.h>
 #include <pcl/common/transforms.h>
 #include <pcl/features/normal_3d.h>
@@ -640,6 +641,67 @@ TEST(IterativeClosestPointGolden) {
   EXPECT(!reg.hasConverged());  // icp.hpp:103-108
 }
 
+// ---- test/registration/test_registration.cpp:240-295 ------------------------------------------------
+// The reference test runs ICP on PointNormal clouds with a point-to-plane estimator set through
+// setTransformationEstimation and only asserts convergence (its matrix check is commented out: "different results on
+// 32 vs 64-bit").  It uses the Levenberg-Marquardt estimator (out of scope here); this is the same set-up with the
+// linear least-squares one (:324-374), whose loop runs on the device.
+TEST(IterativeClosestPoint_PointToPlaneLLS) {
+  typedef PointNormal PointT;
+  PointCloud<PointT>::Ptr src(new PointCloud<PointT>);
+  copyPointCloud(cloud_source, *src);
+  PointCloud<PointT>::Ptr tgt(new PointCloud<PointT>);
+  copyPointCloud(cloud_target, *tgt);
+  EXPECT(src->size() == cloud_source.size() && (*src)[7].x == cloud_source[7].x && (*src)[7].normal_x == 0.f);
+  PointCloud<PointT> output;
+  NormalEstimation<PointNormal, PointNormal> norm_est;
+  norm_est.setSearchMethod(search::KdTree<PointNormal>::Ptr(new search::KdTree<PointNormal>));
+  norm_est.setKSearch(10);
+  norm_est.setInputCloud(tgt);
+  norm_est.compute(*tgt);
+  EXPECT((*tgt)[7].x == cloud_target[7].x && std::isfinite((*tgt)[7].normal_x) && (*tgt)[7].normal_x != 0.f);
+  IterativeClosestPoint<PointT, PointT> reg;
+  typedef registration::TransformationEstimationPointToPlaneLLS<PointT, PointT> PointToPlane;
+  std::shared_ptr<PointToPlane> point_to_plane(new PointToPlane);
+  reg.setTransformationEstimation(point_to_plane);
+  reg.setInputCloud(src);
+  reg.setInputTarget(tgt);
+  reg.setMaximumIterations(50);
+  reg.setTransformationEpsilon(1e-8);
+  reg.align(output);
+  EXPECT_EQ(int(output.points.size()), int(cloud_source.points.size()));
+  EXPECT(reg.hasConverged());
+  EXPECT(reg.getFitnessScore() < 0.001);
+  // the loop is the C ABI's: same transform from pclmi_icp_align_point_to_plane on the same data
+  pclmi_tree *t = nullptr;
+  EXPECT(pclmi_tree_create(&(*tgt)[0].x, tgt->size(), sizeof(PointT), nullptr, 0, 0, &t) == PCLMI_OK);
+  pclmi_icp_params p;
+  pclmi_icp_default_params(&p);
+  p.max_iterations = 50;
+  p.transformation_epsilon = 1e-8;
+  float T[16];
+  pclmi_icp_stats st;
+  EXPECT(pclmi_icp_align_point_to_plane(&p, t, &(*src)[0].x, src->size(), sizeof(PointT), &(*src)[0].normal_x,
+                                        sizeof(PointT), &(*tgt)[0].normal_x, tgt->size(), sizeof(PointT), nullptr,
+                                        nullptr, T, nullptr, &st) == PCLMI_OK);
+  Matrix4f F = reg.getFinalTransformation();
+  for (int i = 0; i < 16; ++i) EXPECT(F.data()[i] == T[i]);
+  EXPECT(st.iterations == reg.getNumberOfIterations());
+  pclmi_tree_destroy(t);
+  // the output is the source under the final transform, normals untouched (transformPointCloud, icp.hpp:174)
+  double worst = 0;
+  for (size_t i = 0; i < output.size(); ++i) {
+    const PointT &s = (*src)[i];
+    const float x = ((F(0, 0) * s.x + F(0, 1) * s.y) + F(0, 2) * s.z) + F(0, 3);
+    worst = std::max(worst, double(std::fabs(x - output[i].x)));
+  }
+  EXPECT(worst < 1e-4);
+  // RANSAC off: the fully device-resident loop reaches the same basin
+  reg.setRANSACIterations(0);
+  reg.align(output);
+  EXPECT(reg.hasConverged() && reg.getFitnessScore() < 0.001);
+}
+
 int main(int argc, char **argv) {
   g_dir = argc > 1 ? argv[1] : "tests/golden";
   if (pclmi_device_count() <= 0) {
@@ -663,6 +725,7 @@ int main(int argc, char **argv) {
   RUN(getApproximateIndices_equals_per_point_search);
   RUN(RegistrationAPI);
   RUN(IterativeClosestPointGolden);
+  RUN(IterativeClosestPoint_PointToPlaneLLS);
   std::printf("%d checks, %d failed\n", g_checks, g_fail);
   return g_fail ? 1 : 0;
 }
