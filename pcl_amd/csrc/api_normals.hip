@@ -1,5 +1,6 @@
 // api_normals.hip - C ABI: surface normals (NormalEstimation) on top of the batched searches.
 #include <cmath>
+#include <cstdlib>
 #include <limits>
 #include <vector>
 
@@ -33,6 +34,21 @@ int pclmi_normals_dev(const pclmi_tree *t, const float *d_q, size_t nq, size_t q
   }
   if (k > 0) {
     const int k_eff = (size_t)k > t->n ? (int)t->n : k;
+    static const bool unfused = [] {  // development switch: PCLMI_NORMALS=split runs search and plane fit separately
+      const char *e = getenv("PCLMI_NORMALS");
+      return e && e[0] == 's';
+    }();
+    if (knn_normals_fused(k_eff) && !unfused) {
+      // ONE kernel: the lane that finds a point's k neighbours fits the plane (knn_kernels.hip normals_finish); the
+      // neighbour lists never reach HBM
+      WsGuard g(t, s);
+      PCLMI_CHECK(g.w, PCLMI_ERR_OOM, "no workspace");
+      const int32_t *order = nullptr;
+      RC(launch_morton_order(t, g.w, d_q, nq, qsf, nullptr, nullptr, s, &order));
+      RC(launch_knn_normals(t, d_q, nq, qsf, order, k_eff, vp, d_normals, s));
+      PCLMI_HIP(hipStreamSynchronize(s));
+      return PCLMI_OK;
+    }
     // neighbour lists of the whole batch: one search launch (the reference loops over points, feature.hpp:188-220)
     // (buffers come from the library's result-buffer cache: no hipMalloc / hipFree in the steady state)
     int *idx = (int *)dev_cache_get(nq * (size_t)k_eff * sizeof(int));
@@ -48,6 +64,19 @@ int pclmi_normals_dev(const pclmi_tree *t, const float *d_q, size_t nq, size_t q
     dev_cache_put(d2);
     if (rc) return rc;
     if (e != hipSuccess) return hip_fail(e, "normals", __FILE__, __LINE__);
+    return PCLMI_OK;
+  }
+  static const bool split_radius = [] {  // development switch, as above
+    const char *e = getenv("PCLMI_NORMALS");
+    return e && e[0] == 's';
+  }();
+  if (!split_radius) {
+    // ONE traversal: hits are folded into the plane-fit moments as they are found (radius_kernels.hip); the
+    // variable-length neighbour lists (count pass, scan, fill, sort, CSR arrays) are never built
+    WsGuard g(t, s);
+    PCLMI_CHECK(g.w, PCLMI_ERR_OOM, "no workspace");
+    RC(radius_normals_dev(t, g.w, d_q, nq, qsf, (float)(radius * radius), vp, d_normals, s));  // kdtree_flann.hpp:140
+    PCLMI_HIP(hipStreamSynchronize(s));
     return PCLMI_OK;
   }
   DevBuf<uint64_t> off;

@@ -37,6 +37,7 @@
 #ifndef PCLMI_IX32
 #define PCLMI_IX32 80
 #endif
+#include "eig3.hpp"
 #include "pclmi_internal.h"
 #include "traverse.hpp"
 
@@ -196,11 +197,82 @@ __device__ __forceinline__ void knn_finish(unsigned int (*buf)[64], const float4
   }
 }
 
-template <int K, int C, int WPB>
+// Epilogue of the FUSED surface-normal search (NormalEstimation::computeFeature, features/impl/normal_3d.hpp:46-98):
+// instead of storing the k neighbours and gathering them again in a second kernel, the lane that has just found them
+// accumulates the plane-fit moments (computeMeanAndCovarianceMatrix, common/impl/centroid.hpp:553-617; fp64, about
+// the query point) from the bucket-slot rows its buffer points at - rows it touched a moment ago -, solves for the
+// smallest eigenpair (solvePlaneParameters, features/impl/feature.hpp:47-86), flips the normal towards the viewpoint
+// (normal_3d.h:162-181) and stores 16 bytes per query instead of 8 k.  The neighbour SET is the one pclmi_knn returns
+// (the k smallest (d2, index) keys); the order of the fp64 additions differs from the two-kernel path's by
+// roundings some 1e-9 below the fp32 result.
+template <int K, int C>
+__device__ __forceinline__ void normals_finish(unsigned int (*buf)[64], const float4 *__restrict__ cloud,
+                                               const LaneQuery &lq, int lane, int cnt, float tau, int k_out, float vpx,
+                                               float vpy, float vpz, float4 *__restrict__ out) {
+  const float qx = lq.x, qy = lq.y, qz = lq.z;
+  unsigned long long kth = ~0ull;
+  if (k_out < K) {
+    // fewer neighbours asked for than the kernel keeps: the cut is the k_out-th smallest (d2, index) key
+    float dk[K];
+    unsigned int ik[K];
+    cnt = compact_index_buffer<K, C>(buf, cloud, qx, qy, qz, lane, cnt, tau, dk, ik, true);
+    unsigned long long key[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) key[j] = j < cnt ? (((unsigned long long)__float_as_uint(dk[j]) << 32) | ik[j]) : ~0ull;
+    sort_keys<K>(key);
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+      if (j == k_out - 1) kth = key[j];
+  } else {
+    float dk[K];
+    unsigned int ik[K];
+    cnt = compact_index_buffer<K, C>(buf, cloud, qx, qy, qz, lane, cnt, tau, dk, ik, false);  // <= K survivors
+  }
+  double s1x = 0, s1y = 0, s1z = 0, xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0, n = 0;
+#pragma unroll
+  for (int j0 = 0; j0 < K; j0 += 8) {
+    float4 p[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      p[u] = (j0 + u < K && j0 + u < cnt) ? cloud[buf[min(j0 + u, C - 1)][lane]] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (j0 + u >= K) continue;
+      bool member = j0 + u < cnt;
+      if (k_out < K) {
+        const float d = sq3(qx - p[u].x, qy - p[u].y, qz - p[u].z);
+        member = member && ((((unsigned long long)__float_as_uint(d) << 32) | __float_as_uint(p[u].w)) <= kth);
+      }
+      if (member) {
+        const double dx = (double)p[u].x - (double)qx, dy = (double)p[u].y - (double)qy, dz = (double)p[u].z - (double)qz;
+        n += 1.0;
+        s1x += dx; s1y += dy; s1z += dz;
+        xx += dx * dx; xy += dx * dy; xz += dx * dz;
+        yy += dy * dy; yz += dy * dz; zz += dz * dz;
+      }
+    }
+  }
+  if (!lq.alive) return;
+  const float nanf_ = __builtin_nanf("");
+  float4 res = make_float4(nanf_, nanf_, nanf_, nanf_);
+  if (lq.searchable && n > 0.0) {
+    const double s1[3] = {s1x, s1y, s1z}, s2[6] = {xx, xy, xz, yy, yz, zz}, o[3] = {qx, qy, qz};
+    double plane[4], curv;
+    eig::plane_from_moments(n, s1, s2, o, plane, curv);
+    const double c = ((double)vpx - qx) * plane[0] + ((double)vpy - qy) * plane[1] + ((double)vpz - qz) * plane[2];
+    const double sgn = c < 0.0 ? -1.0 : 1.0;
+    res = make_float4((float)(sgn * plane[0]), (float)(sgn * plane[1]), (float)(sgn * plane[2]), (float)curv);
+  }
+  out[lq.qi] = res;
+}
+
+// NRM: the fused surface-normal variant - out_d2 then receives nq x (nx, ny, nz, curvature), out_idx is unused
+template <int K, int C, int WPB, bool NRM = false>
 __global__ __launch_bounds__(64 * WPB) void knn_union_ix_kernel(TreeView t, const float *__restrict__ q,
                                                                  int q_stride_f, const int *__restrict__ order,
                                                                  int nq, int k_out, int *__restrict__ out_idx,
-                                                                 float *__restrict__ out_d2) {
+                                                                 float *__restrict__ out_d2, float vpx, float vpy,
+                                                                 float vpz) {
   static_assert(C >= K + 8, "buffer must hold the K best plus two groups of appends");
   __shared__ unsigned int lds[WPB][C][64];
   const int lane = threadIdx.x & 63;
@@ -274,7 +346,10 @@ __global__ __launch_bounds__(64 * WPB) void knn_union_ix_kernel(TreeView t, cons
   }
   PCLMI_STAT(6, 1);
 
-  knn_finish<K, C>(buf, cloud, lq, lane, cnt, a[K - 1], k_out, out_idx, out_d2);
+  if constexpr (NRM)
+    normals_finish<K, C>(buf, cloud, lq, lane, cnt, a[K - 1], k_out, vpx, vpy, vpz, reinterpret_cast<float4 *>(out_d2));
+  else
+    knn_finish<K, C>(buf, cloud, lq, lane, cnt, a[K - 1], k_out, out_idx, out_d2);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -283,10 +358,11 @@ __global__ __launch_bounds__(64 * WPB) void knn_union_ix_kernel(TreeView t, cons
 // against ~10 per query), and every lane walking for itself (traverse.hpp lane_traverse) wins although its loads
 // diverge.  Same bookkeeping as the union kernel: K running distances in registers, index-only append buffer in
 // LDS, compaction when a bucket's worth of room is no longer free, shared epilogue.
-template <int K, int C>
+template <int K, int C, bool NRM = false>
 __global__ __launch_bounds__(64) void knn_lane_ix_kernel(TreeView t, const float *__restrict__ q, int q_stride_f,
                                                          const int *__restrict__ order, int nq, int levels, int k_out,
-                                                         int *__restrict__ out_idx, float *__restrict__ out_d2) {
+                                                         int *__restrict__ out_idx, float *__restrict__ out_d2,
+                                                         float vpx, float vpy, float vpz) {
   static_assert(C >= K + L + 8, "buffer must hold the K best plus one bucket of appends");
   extern __shared__ float far_lds[];  // levels x 64 floats
   __shared__ unsigned int lds[C][64];
@@ -328,7 +404,10 @@ __global__ __launch_bounds__(64) void knn_lane_ix_kernel(TreeView t, const float
       [&] {  // once per round, wave converged: make room for the next bucket
         if (__any(cnt > C - L)) cnt = compact_index_buffer<K, C>(buf, cloud, qx, qy, qz, lane, cnt, a[K - 1], dk, ik, false);
       });
-  knn_finish<K, C>(buf, cloud, lq, lane, cnt, a[K - 1], k_out, out_idx, out_d2);
+  if constexpr (NRM)
+    normals_finish<K, C>(buf, cloud, lq, lane, cnt, a[K - 1], k_out, vpx, vpy, vpz, reinterpret_cast<float4 *>(out_d2));
+  else
+    knn_finish<K, C>(buf, cloud, lq, lane, cnt, a[K - 1], k_out, out_idx, out_d2);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -734,23 +813,33 @@ int launch_morton_order(const pclmi_tree *t, Workspace *w, const float *d_q, siz
   return PCLMI_OK;
 }
 
+// vp != nullptr: the fused surface-normal variant (d_d2 receives nq x 4 floats, d_idx is unused)
 template <int K, int C, int WPB>
 static void launch_union_ix(const pclmi_tree *t, const float *d_q, size_t nq, size_t qsf, const int32_t *order,
-                            int k_eff, int32_t *d_idx, float *d_d2, hipStream_t s) {
+                            int k_eff, int32_t *d_idx, float *d_d2, hipStream_t s, const float *vp = nullptr) {
   unsigned waves = (unsigned)((nq + 63) / 64);
   unsigned blocks = (waves + WPB - 1) / WPB;
   blocks = (blocks + 7) & ~7u;
-  hipLaunchKernelGGL((knn_union_ix_kernel<K, C, WPB>), dim3(blocks), dim3(64 * WPB), 0, s, t->view(), d_q,
-                     (int)qsf, order, (int)nq, k_eff, d_idx, d_d2);
+  if (vp)
+    hipLaunchKernelGGL((knn_union_ix_kernel<K, C, WPB, true>), dim3(blocks), dim3(64 * WPB), 0, s, t->view(), d_q,
+                       (int)qsf, order, (int)nq, k_eff, d_idx, d_d2, vp[0], vp[1], vp[2]);
+  else
+    hipLaunchKernelGGL((knn_union_ix_kernel<K, C, WPB, false>), dim3(blocks), dim3(64 * WPB), 0, s, t->view(), d_q,
+                       (int)qsf, order, (int)nq, k_eff, d_idx, d_d2, 0.f, 0.f, 0.f);
 }
 
 template <int K, int C>
 static void launch_lane_ix(const pclmi_tree *t, const float *d_q, size_t nq, size_t qsf, const int32_t *order,
-                           int k_eff, int32_t *d_idx, float *d_d2, hipStream_t s) {
+                           int k_eff, int32_t *d_idx, float *d_d2, hipStream_t s, const float *vp = nullptr) {
   const int levels = lane_nearest_levels(t->M);
   const unsigned blocks = (((unsigned)((nq + 63) / 64)) + 7) & ~7u;
-  hipLaunchKernelGGL((knn_lane_ix_kernel<K, C>), dim3(blocks), dim3(64), (size_t)levels * 64 * sizeof(float), s, t->view(),
-                     d_q, (int)qsf, order, (int)nq, levels, k_eff, d_idx, d_d2);
+  const size_t lds = (size_t)levels * 64 * sizeof(float);
+  if (vp)
+    hipLaunchKernelGGL((knn_lane_ix_kernel<K, C, true>), dim3(blocks), dim3(64), lds, s, t->view(), d_q, (int)qsf, order,
+                       (int)nq, levels, k_eff, d_idx, d_d2, vp[0], vp[1], vp[2]);
+  else
+    hipLaunchKernelGGL((knn_lane_ix_kernel<K, C, false>), dim3(blocks), dim3(64), lds, s, t->view(), d_q, (int)qsf, order,
+                       (int)nq, levels, k_eff, d_idx, d_d2, 0.f, 0.f, 0.f);
 }
 
 // sparse batch: the per-lane kernels (measured crossover); PCLMI_KNN=union / lane forces one
@@ -780,6 +869,35 @@ const char *knn_kernel_name(const pclmi_tree *t, size_t nq, int k_eff) {
   if (k_eff <= 16) return "knn_union_ix_kernel<16," PCLMI_STR(PCLMI_IX16) ",1>";
   if (k_eff <= 32) return "knn_union_ix_kernel<32," PCLMI_STR(PCLMI_IX32) ",1>";
   return "knn_heap_kernel";
+}
+
+bool knn_normals_fused(int k_eff) { return k_eff >= 2 && k_eff <= 32; }
+
+// the fused search + plane fit (normals_finish) for 2 <= k_eff <= 32: d_out receives nq x (nx, ny, nz, curvature)
+int launch_knn_normals(const pclmi_tree *t, const float *d_q, size_t nq, size_t qsf, const int32_t *order, int k_eff,
+                       const float vp[3], float *d_out, hipStream_t s) {
+  if (nq == 0) return PCLMI_OK;
+  PCLMI_CHECK(knn_normals_fused(k_eff), PCLMI_ERR_INVALID, "fused normals need 2 <= k <= 32 (got %d)", k_eff);
+  PCLMI_CHECK(nq < (size_t)1 << 31, PCLMI_ERR_UNSUPPORTED, "more than 2^31-1 queries in one call");
+  TimingScope ts(PCLMI_TIMER_KNN, s);
+  if (knn_sparse(t, nq)) {
+    if (k_eff <= 4) launch_lane_ix<4, 32>(t, d_q, nq, qsf, order, k_eff, nullptr, d_out, s, vp);
+    else if (k_eff <= 8) launch_lane_ix<8, 32>(t, d_q, nq, qsf, order, k_eff, nullptr, d_out, s, vp);
+    else if (k_eff <= 16) launch_lane_ix<16, 40>(t, d_q, nq, qsf, order, k_eff, nullptr, d_out, s, vp);
+    else launch_lane_ix<32, 64>(t, d_q, nq, qsf, order, k_eff, nullptr, d_out, s, vp);
+  } else if (k_eff <= 2) {
+    launch_union_ix<2, 16, 1>(t, d_q, nq, qsf, order, k_eff, nullptr, d_out, s, vp);
+  } else if (k_eff <= 4) {
+    launch_union_ix<4, 16, 1>(t, d_q, nq, qsf, order, k_eff, nullptr, d_out, s, vp);
+  } else if (k_eff <= 8) {
+    launch_union_ix<8, PCLMI_IX8, 1>(t, d_q, nq, qsf, order, k_eff, nullptr, d_out, s, vp);
+  } else if (k_eff <= 16) {
+    launch_union_ix<16, PCLMI_IX16, 1>(t, d_q, nq, qsf, order, k_eff, nullptr, d_out, s, vp);
+  } else {
+    launch_union_ix<32, PCLMI_IX32, 1>(t, d_q, nq, qsf, order, k_eff, nullptr, d_out, s, vp);
+  }
+  PCLMI_HIP(hipGetLastError());
+  return PCLMI_OK;
 }
 
 int launch_knn(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, size_t qsf,

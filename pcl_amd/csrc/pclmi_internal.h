@@ -201,6 +201,10 @@ int launch_morton_order(const pclmi_tree *t, Workspace *w, const float *d_q, siz
 const char *knn_kernel_name(const pclmi_tree *t, size_t nq, int k_eff);
 int launch_knn(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, size_t q_stride_f,
                const int32_t *d_order, int k_eff, int32_t *d_idx, float *d_d2, hipStream_t s);
+// the search fused with the surface-normal plane fit (k-NN neighbourhoods with knn_normals_fused(k_eff))
+bool knn_normals_fused(int k_eff);
+int launch_knn_normals(const pclmi_tree *t, const float *d_q, size_t nq, size_t q_stride_f, const int32_t *d_order,
+                       int k_eff, const float vp[3], float *d_out, hipStream_t s);
 
 
 // ---- k-NN entry-point plumbing (api_core.hip), shared by pclmi_knn_dev / _async / _noalloc ----
@@ -219,6 +223,10 @@ void dev_cache_put(void *p);       // nullptr is ignored
 int radius_search_dev(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, size_t q_stride_f,
                       float r2, uint32_t max_nn, int sorted, uint64_t *d_offsets, int32_t **d_idx,
                       float **d_d2, uint64_t *total, hipStream_t s);
+
+// the radius search fused with the surface-normal plane fit: no neighbour list is materialised
+int radius_normals_dev(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, size_t q_stride_f, float r2,
+                       const float vp[3], float *d_out, hipStream_t s);
 
 // ---- ICP / registration kernels (icp_kernels.hip) -----------------------------------------
 struct Xf {

@@ -21,6 +21,7 @@
 
 #include <hipcub/hipcub.hpp>
 
+#include "eig3.hpp"
 #include "pclmi_internal.h"
 #include "traverse.hpp"
 
@@ -159,6 +160,158 @@ __global__ __launch_bounds__(64) void radius_lane_kernel(TreeView t, const float
     const int over = __popcll(__ballot(cnt > (unsigned int)PROV_CAP));
     if (over && lane == 0) atomicAdd(n_over, (unsigned int)over);
   }
+}
+
+// ---- fused radius search + surface normal ----------------------------------------------------------
+// NormalEstimation with setRadiusSearch (features/impl/normal_3d.hpp:46-98 over Feature's radius binding,
+// features/impl/feature.hpp:143-159): the plane fit needs the SUM of the neighbours' moments, not the list, so the
+// variable-length output of the radius search (count pass, scan, fill / sort, CSR arrays) never has to exist.  Every
+// hit's bucket slot goes into a small per-lane LDS buffer; when a bucket's worth of room is no longer free the lanes
+// drain their own entries - gather the slot row (touched a moment ago), add the fp64 moments about the query point.
+// Draining per lane (not per candidate under the wave's union mask) keeps the fp64 work proportional to a lane's own
+// hits.  The epilogue is the one of the k-NN variant (knn_kernels.hip normals_finish): smallest eigenpair,
+// curvature, flip towards the viewpoint, 16 bytes per query.
+constexpr int RN_C = 32;  // buffer entries per lane (>= 2 buckets)
+struct MomentAcc {
+  double n = 0, sx = 0, sy = 0, sz = 0, xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0;
+  __device__ __forceinline__ void drain(unsigned int (*buf)[64], int lane, int &cnt, const float4 *__restrict__ rows,
+                                        float qx, float qy, float qz) {
+    int mx = cnt;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+    for (int e = 0; e < mx; e += 8) {
+      float4 p[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        p[u] = (e + u < cnt) ? rows[buf[min(e + u, RN_C - 1)][lane]] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (e + u < cnt) {
+          const double dx = (double)p[u].x - (double)qx, dy = (double)p[u].y - (double)qy, dz = (double)p[u].z - (double)qz;
+          n += 1.0;
+          sx += dx; sy += dy; sz += dz;
+          xx += dx * dx; xy += dx * dy; xz += dx * dz;
+          yy += dy * dy; yz += dy * dz; zz += dz * dz;
+        }
+      }
+    }
+    cnt = 0;
+  }
+  __device__ __forceinline__ void finish(const LaneQuery &lq, float vpx, float vpy, float vpz, float4 *__restrict__ out) {
+    if (!lq.alive) return;
+    const float nanf_ = __builtin_nanf("");
+    float4 res = make_float4(nanf_, nanf_, nanf_, nanf_);
+    if (lq.searchable && n > 0.0) {
+      const double s1[3] = {sx, sy, sz}, s2[6] = {xx, xy, xz, yy, yz, zz}, o[3] = {lq.x, lq.y, lq.z};
+      double plane[4], curv;
+      eig::plane_from_moments(n, s1, s2, o, plane, curv);
+      const double c = ((double)vpx - lq.x) * plane[0] + ((double)vpy - lq.y) * plane[1] + ((double)vpz - lq.z) * plane[2];
+      const double sgn = c < 0.0 ? -1.0 : 1.0;
+      res = make_float4((float)(sgn * plane[0]), (float)(sgn * plane[1]), (float)(sgn * plane[2]), (float)curv);
+    }
+    out[lq.qi] = res;
+  }
+};
+
+constexpr int RN_WPB = 2;
+__global__ __launch_bounds__(64 * RN_WPB) void radius_normals_union_kernel(TreeView t, const float *__restrict__ q,
+                                                                           int q_stride_f,
+                                                                           const int *__restrict__ order, int nq,
+                                                                           float r2, float tau_r, float vpx, float vpy,
+                                                                           float vpz, float4 *__restrict__ out) {
+  __shared__ unsigned int lds[RN_WPB][RN_C][64];
+  const int lane = threadIdx.x & 63;
+  LaneQuery lq;
+  if (!load_lane_query<RN_WPB>(q, q_stride_f, order, nq, lq)) return;
+  const float qx = lq.x, qy = lq.y, qz = lq.z;
+  const float tau = lq.searchable ? tau_r : -1.f;
+  unsigned int(*buf)[64] = lds[threadIdx.x >> 6];
+  const float4 *rows = reinterpret_cast<const float4 *>(t.slot);
+  int cnt = 0;
+  MomentAcc acc;
+  LaneStack st{0, 0, lane};
+  st.push(1);
+  const cbox_ptr box = (cbox_ptr)t.box;
+  const cgrp_ptr box2 = (cgrp_ptr)t.box;
+  const cgrp_ptr leaf = (cgrp_ptr)t.leaf;
+  const int M = t.M;
+  while (st.sp > 0) {
+    const int node = st.pop();
+    if (node >= M) {
+      const f8v b = box[node];
+      const cgrp_ptr rec = leaf + (size_t)(node - M) * G;
+      f16v grp[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) grp[g] = rec[g];
+      if (!__any(box_dist(qx, qy, qz, b[0], b[1], b[2], b[3], b[4], b[5]) <= tau)) continue;
+      if (__any(cnt > RN_C - L)) acc.drain(buf, lane, cnt, rows, qx, qy, qz);
+      const f2v q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        float dd[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f2v d2 = sq3_pk(q2x - f2v{grp[g][2 * h], grp[g][2 * h + 1]},
+                                q2y - f2v{grp[g][4 + 2 * h], grp[g][5 + 2 * h]},
+                                q2z - f2v{grp[g][8 + 2 * h], grp[g][9 + 2 * h]});
+          dd[2 * h] = d2.x;
+          dd[2 * h + 1] = d2.y;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (dd[j] < r2) {  // strict (kdtree_flann.hpp:115-157); padded slots are at +inf, NaN queries never pass
+            buf[cnt][lane] = (unsigned int)(node - M) * L + g * 4 + j;
+            ++cnt;
+          }
+        }
+      }
+    } else {
+      expand_inner(st, box2, node, M, qx, qy, qz, tau);
+    }
+  }
+  acc.drain(buf, lane, cnt, rows, qx, qy, qz);
+  acc.finish(lq, vpx, vpy, vpz, out);
+}
+
+__global__ __launch_bounds__(64) void radius_normals_lane_kernel(TreeView t, const float *__restrict__ q, int q_stride_f,
+                                                                 const int *__restrict__ order, int nq, int levels,
+                                                                 float r2, float tau_r, float vpx, float vpy, float vpz,
+                                                                 float4 *__restrict__ out) {
+  extern __shared__ float far_lds[];  // levels x 64 floats
+  __shared__ unsigned int buf[RN_C][64];
+  const int lane = threadIdx.x & 63;
+  LaneQuery lq;
+  if (!load_lane_query<1>(q, q_stride_f, order, nq, lq)) return;
+  const float qx = lq.x, qy = lq.y, qz = lq.z;
+  const float4 *rows = reinterpret_cast<const float4 *>(t.slot);
+  int cnt = 0;
+  MomentAcc acc;
+  const f2v q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
+  lane_traverse(
+      t, qx, qy, qz, lq.searchable, tau_r, reinterpret_cast<float(*)[64]>(far_lds), lane, 1,
+      [&](int leafno, float tau) {
+        const float4 *rec = reinterpret_cast<const float4 *>(t.leaf + (size_t)leafno * (4 * L));
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const float4 X = rec[g * 4 + 0], Y = rec[g * 4 + 1], Z = rec[g * 4 + 2];
+          const f2v d01 = sq3_pk(q2x - f2v{X.x, X.y}, q2y - f2v{Y.x, Y.y}, q2z - f2v{Z.x, Z.y});
+          const f2v d23 = sq3_pk(q2x - f2v{X.z, X.w}, q2y - f2v{Y.z, Y.w}, q2z - f2v{Z.z, Z.w});
+          const float dd[4] = {d01.x, d01.y, d23.x, d23.y};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (dd[j] < r2) {
+              buf[cnt][lane] = (unsigned int)leafno * L + g * 4 + j;
+              ++cnt;
+            }
+          }
+        }
+        return tau;
+      },
+      [&] {  // once per round, wave converged: make room for the next bucket
+        if (__any(cnt > RN_C - L)) acc.drain(buf, lane, cnt, rows, qx, qy, qz);
+      });
+  acc.drain(buf, lane, cnt, rows, qx, qy, qz);
+  acc.finish(lq, vpx, vpy, vpz, reinterpret_cast<float4 *>(out));
 }
 
 template <int MODE>
@@ -516,6 +669,39 @@ int sort_segments(Workspace *w, u64 *keys, u64 *alt, const u64 *d_offsets, size_
 }
 
 }  // namespace
+
+// the fused radius search + plane fit: d_out receives nq x (nx, ny, nz, curvature); NaN rows where no neighbour exists
+int radius_normals_dev(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, size_t qsf, float r2,
+                       const float vp[3], float *d_out, hipStream_t s) {
+  PCLMI_CHECK(nq < ((size_t)1 << 31) - 1, PCLMI_ERR_UNSUPPORTED, "more than 2^31-2 queries in one call");
+  if (nq == 0) return PCLMI_OK;
+  if (t->n == 0 || !(r2 > 0.f)) {  // no neighbour anywhere: every normal is NaN (the 0xff byte pattern is a NaN)
+    PCLMI_HIP(hipMemsetAsync(d_out, 0xff, nq * 4 * sizeof(float), s));
+    return PCLMI_OK;
+  }
+  const int32_t *order = nullptr;
+  RC(launch_morton_order(t, w, d_q, nq, qsf, nullptr, nullptr, s, &order));
+  const float tau_r = nextafterf(r2, 0.f);
+  static const int forced = [] {
+    const char *e = getenv("PCLMI_KNN");
+    return !e ? 0 : (e[0] == 'u' ? 1 : (e[0] == 'l' ? 2 : 0));
+  }();
+  const bool per_lane = forced ? forced == 2 : nq * 4 < t->n;
+  const unsigned waves = (unsigned)((nq + 63) / 64);
+  TimingScope ts(PCLMI_TIMER_RADIUS, s);
+  if (per_lane) {
+    const int levels = lane_nearest_levels(t->M);
+    hipLaunchKernelGGL(radius_normals_lane_kernel, dim3((waves + 7) & ~7u), dim3(64), (size_t)levels * 64 * sizeof(float),
+                       s, t->view(), d_q, (int)qsf, order, (int)nq, levels, r2, tau_r, vp[0], vp[1], vp[2],
+                       reinterpret_cast<float4 *>(d_out));
+  } else {
+    const unsigned blocks = ((waves + RN_WPB - 1) / RN_WPB + 7) & ~7u;
+    hipLaunchKernelGGL(radius_normals_union_kernel, dim3(blocks), dim3(64 * RN_WPB), 0, s, t->view(), d_q, (int)qsf,
+                       order, (int)nq, r2, tau_r, vp[0], vp[1], vp[2], reinterpret_cast<float4 *>(d_out));
+  }
+  PCLMI_HIP(hipGetLastError());
+  return PCLMI_OK;
+}
 
 int radius_search_dev(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, size_t qsf, float r2,
                       uint32_t max_nn, int sorted, uint64_t *d_offsets, int32_t **d_idx, float **d_d2,
