@@ -87,10 +87,20 @@ int pclmi_timing_pending(void);
  * selects the rows to index, as the IndicesConstPtr overload does (:214-249); returned
  * neighbour indices are always rows of the whole cloud (the reference's index_mapping_).
  * Rows with a non-finite coordinate are skipped (:199-203).  The cloud is copied: later
- * edits do not affect the tree.  leaf_max <= 0 selects the default bucket size.
+ * edits do not affect the tree.  leaf_max is accepted for signature compatibility and IGNORED: the bucket size
+ * (16 points) is a compile-time constant of the kernels, and no search result depends on it.
  * An empty cloud yields a valid empty tree (searches return 0 neighbours). */
 int pclmi_tree_create(const float *xyz, size_t n, size_t stride_bytes, const int32_t *indices,
                       size_t n_indices, int leaf_max, pclmi_tree **out);
+/* The same from a cloud that already lives in DEVICE memory (d_xyz / d_indices are device pointers): nothing crosses
+ * PCIe.  The reference rebuilds the target tree on every determineCorrespondences
+ * (registration/include/pcl/registration/impl/correspondence_estimation.hpp:47-63), so for a device-resident
+ * pipeline the build is on the path.  Built entirely on the GPU (three radix sorts + one stable partition per tree
+ * level); pclmi_tree_create uploads the caller's rows once and takes the same route.  The work is enqueued on
+ * `stream` (NULL: the tree's own stream - the cloud must then be complete when the call is made); the call returns
+ * after the build has finished.  Up to 2^29-1 rows. */
+int pclmi_tree_create_dev(const float *d_xyz, size_t n, size_t stride_bytes, const int32_t *d_indices,
+                          size_t n_indices, void *stream, pclmi_tree **out);
 void pclmi_tree_destroy(pclmi_tree *t);
 /* Number of indexed (finite, selected) points = total_nr_points_ (:70). */
 size_t pclmi_tree_size(const pclmi_tree *t);

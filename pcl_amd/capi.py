@@ -64,6 +64,8 @@ SIGNATURES = {
     "pclmi_timing_pending": (C.c_int, []),
     "pclmi_tree_create": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int,
                                     C.POINTER(C.c_void_p)]),
+    "pclmi_tree_create_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
+                                        C.POINTER(C.c_void_p)]),
     "pclmi_tree_destroy": (None, [C.c_void_p]),
     "pclmi_tree_size": (C.c_size_t, [C.c_void_p]),
     "pclmi_knn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p,
@@ -250,6 +252,31 @@ class Tree:
                                      C.byref(h)))
         self.h = h
         self._shards = 0  # live IcpShard contexts holding a raw pointer to this tree
+
+    @classmethod
+    def from_device(cls, xyz_ptr, n, stride_bytes, indices_ptr=None, n_indices=0, stream=None):
+        """pclmi_tree_create_dev: the cloud (and the optional index list) already live in device memory."""
+        self = cls.__new__(cls)
+        self.cloud = None
+        self._shards = 0
+        h = C.c_void_p()
+        _check(load_library().pclmi_tree_create_dev(xyz_ptr, n, stride_bytes, indices_ptr, n_indices, stream, C.byref(h)))
+        self.h = h
+        return self
+
+    def debug_arrays(self):
+        """(box[2M, 8], leaf[M, 64]) of the device tree (development aid, pclmi_debug_tree_download)."""
+        lib = load_library()
+        fn = lib.pclmi_debug_tree_download
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
+        m = C.c_int(0)
+        _check(fn(self.h, C.byref(m), None, None))
+        box = np.zeros((2 * m.value, 8), np.float32)
+        leaf = np.zeros((m.value, 64), np.float32)
+        if m.value:
+            _check(fn(self.h, C.byref(m), box.ctypes.data, leaf.ctypes.data))
+        return box, leaf
 
     def close(self):
         if getattr(self, "h", None):

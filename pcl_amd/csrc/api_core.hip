@@ -410,6 +410,56 @@ int pclmi_timing_read(int which, double *total_ms, uint64_t *launches, int reset
   return PCLMI_OK;
 }
 
+// development switch PCLMI_TREE_BUILD=host: build the tree with tree_build.cpp and upload it (the device builder,
+// tree_build_dev.hip, produces the same tree; tests compare the two)
+static bool tree_build_on_host() {
+  const char *e = getenv("PCLMI_TREE_BUILD");  // read per call: tests build both ways in one process
+  return e && e[0] == 'h';
+}
+
+// development aid (not in pclmi.h): the tree's node boxes [2M][8] and leaf records [M][4 * 16] copied to the host;
+// box == NULL only reports M
+int pclmi_debug_tree_download(const pclmi_tree *t, int *M, float *box, float *leaf) {
+  PCLMI_CHECK(t && M, PCLMI_ERR_INVALID, "NULL argument");
+  *M = t->M;
+  if (!box || !leaf || t->M == 0) return PCLMI_OK;
+  PCLMI_HIP(hipSetDevice(t->device));
+  PCLMI_HIP(hipMemcpy(box, t->d_box, (size_t)2 * t->M * 8 * sizeof(float), hipMemcpyDeviceToHost));
+  PCLMI_HIP(hipMemcpy(leaf, t->d_leaf, (size_t)t->M * 4 * kLeafSize * sizeof(float), hipMemcpyDeviceToHost));
+  return PCLMI_OK;
+}
+
+int pclmi_tree_create_dev(const float *d_xyz, size_t n, size_t stride_bytes, const int32_t *d_indices, size_t n_indices,
+                          void *stream, pclmi_tree **out) {
+  PCLMI_CHECK(out != nullptr, PCLMI_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  PCLMI_CHECK(n == 0 || d_xyz != nullptr, PCLMI_ERR_INVALID, "xyz is NULL");
+  PCLMI_CHECK(stride_bytes >= 12 && stride_bytes % 4 == 0, PCLMI_ERR_INVALID,
+              "stride_bytes must be a multiple of 4 and >= 12 (got %zu)", stride_bytes);
+  PCLMI_CHECK(n < ((size_t)1 << 29) && n_indices < ((size_t)1 << 29), PCLMI_ERR_UNSUPPORTED,
+              "the device builder indexes up to 2^29-1 rows");
+  PCLMI_CHECK(pclmi_device_count() > 0, PCLMI_ERR_NO_DEVICE, "no HIP device visible: libpclmi has no CPU fallback");
+  PCLMI_HIP(hipSetDevice(g_device));
+  pclmi_tree *t = new (std::nothrow) pclmi_tree();
+  PCLMI_CHECK(t != nullptr, PCLMI_ERR_OOM, "out of host memory");
+  t->device = g_device;
+  if (hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking) != hipSuccess) {
+    const int code = hip_fail(hipGetLastError(), "hipStreamCreate", __FILE__, __LINE__);
+    pclmi_tree_destroy(t);
+    return code;
+  }
+  // the caller's stream orders the build after whatever produced the cloud; without one the tree's own stream is used
+  // (the cloud must then be complete when the call is made)
+  const int rc = build_device_tree(t, d_xyz, n, stride_bytes / 4, d_indices, n_indices,
+                                   stream ? (hipStream_t)stream : t->stream);
+  if (rc) {
+    pclmi_tree_destroy(t);
+    return rc;
+  }
+  *out = t;
+  return PCLMI_OK;
+}
+
 int pclmi_tree_create(const float *xyz, size_t n, size_t stride_bytes, const int32_t *indices, size_t n_indices,
                       int leaf_max, pclmi_tree **out) {
   (void)leaf_max;  // bucket size is a compile-time constant of the kernels (kLeafSize)
@@ -422,6 +472,18 @@ int pclmi_tree_create(const float *xyz, size_t n, size_t stride_bytes, const int
   PCLMI_CHECK(pclmi_device_count() > 0, PCLMI_ERR_NO_DEVICE,
               "no HIP device visible: libpclmi has no CPU fallback");
   PCLMI_HIP(hipSetDevice(g_device));
+  if (!tree_build_on_host() && n < ((size_t)1 << 29) && n_indices < ((size_t)1 << 29)) {
+    // the cloud crosses PCIe once, as the caller laid it out; everything else happens on the device
+    DevBuf<unsigned char> raw;
+    DevBuf<int32_t> idx;
+    RC(raw.alloc(n * stride_bytes));
+    if (n) PCLMI_HIP(hipMemcpy(raw.p, xyz, n * stride_bytes, hipMemcpyHostToDevice));
+    if (indices) {
+      RC(idx.alloc(n_indices));
+      if (n_indices) PCLMI_HIP(hipMemcpy(idx.p, indices, n_indices * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    return pclmi_tree_create_dev((const float *)raw.p, n, stride_bytes, indices ? idx.p : nullptr, n_indices, nullptr, out);
+  }
   const size_t sf = stride_bytes / 4;
   // convertCloudToArray (impl/kdtree_flann.hpp:180-249): keep finite rows, remember their index
   std::vector<float> pts;

@@ -191,6 +191,10 @@ struct HostTree {
 // pts: n packed xyz (finite), ext: n external row indices
 void build_host_tree(const float *pts, const int32_t *ext, size_t n, HostTree *out);
 
+// ---- device tree builder (tree_build_dev.hip): the same tree, built from a cloud in device memory --------
+int build_device_tree(pclmi_tree *t, const float *d_xyz, size_t n_rows, size_t stride_f, const int32_t *d_indices,
+                      size_t n_indices, hipStream_t s);
+
 // ---- kernels launchers (knn_kernels.hip) -------------------------------------------------
 // order: nullable device permutation (sorted slot -> query row).  bb_lo / bb_hi: box the Morton
 // cells are laid over (NULL = the tree's bounding box).  stable: rows of one cell keep their input order
