@@ -595,6 +595,58 @@ def bench_extras(env, tree, target, q_host, q_dev, stream):
                                "ms_per_iteration": (dt - dt1) / 4 * 1e3, "align_5_iterations_ms": dt * 1e3,
                                "iterations": st.iterations,
                                "last_inliers": st.last_inliers, "status": rc}
+        # ---- the same clouds with TransformationEstimationPointToPlaneLLS in the loop (RANSAC off, device-resident)
+        log("extras: point-to-plane ICP, surface normals, tree build")
+        vp = (512.0, 512.0, 5000.0)
+        tn = capi.normals(t2, tgt, k=16, viewpoint=vp)[:, :3].copy()
+        p = capi.icp_default_params()
+        p.ransac_iterations, p.max_correspondence_distance = 0, 25.0
+        times = {}
+        for iters_pl in (2, 2, 22):
+            p.max_iterations = iters_pl
+            t0 = time.perf_counter()
+            rc, Tpl, _, stpl = capi.icp_align_point_to_plane(t2, src, tn, p)
+            times[iters_pl] = time.perf_counter() - t0
+        ex["icp_point_to_plane"] = {"workload": "configs[3] clouds, target normals from pclmi_normals (k = 16), "
+                                                "pclmi_icp_align_point_to_plane, RANSAC off, one GPU; per-iteration time "
+                                                "= (22-iteration align - 2-iteration align) / 20, so set-up cancels",
+                                    "ms_per_iteration": (times[22] - times[2]) / 20 * 1e3, "iterations": stpl.iterations,
+                                    "status": rc, "max_abs_err_vs_true_transform": float(np.abs(Tpl - T0).max())}
+        # ---- surface normals of every point of the 1M-point cloud (search fused with the plane fit)
+        d_t = torch.from_numpy(tgt).to(dev)
+        d_n = torch.empty((len(tgt), 4), dtype=torch.float32, device=dev)
+        vpc = (C.c_float * 3)(*vp)
+        nrm = {}
+        for name, kk, rr in (("k16", 16, 0.0), ("radius_32_neighbours", 0, r)):
+            for _ in range(2):
+                lib.pclmi_normals_dev(t2.h, d_t.data_ptr(), len(tgt), 12, kk, rr, vpc, d_n.data_ptr(), stream)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                rc = lib.pclmi_normals_dev(t2.h, d_t.data_ptr(), len(tgt), 12, kk, rr, vpc, d_n.data_ptr(), stream)
+            torch.cuda.synchronize()
+            assert rc == 0, lib.pclmi_last_error()
+            nrm[name] = {"value": 5 * len(tgt) / (time.perf_counter() - t0), "unit": "normals/s"}
+        ex["normals_1m"] = {"workload": "NormalEstimation over every point of the 1M-point surface cloud, cloud and "
+                                        "normals in HBM, one fused search + plane-fit kernel per call", **nrm}
+        # ---- tree build (pcl::KdTreeFLANN::setInputCloud): device builder
+        tb = {}
+        for name, cloud_h in (("1m", tgt), ("10m", big)):
+            d_c = torch.from_numpy(cloud_h).to(dev)
+            torch.cuda.synchronize()
+            best_d, best_h = 1e9, 1e9
+            for _ in range(2):
+                t0 = time.perf_counter()
+                tt_ = capi.Tree.from_device(d_c.data_ptr(), len(cloud_h), 12)
+                best_d = min(best_d, time.perf_counter() - t0)
+                tt_.close()
+                t0 = time.perf_counter()
+                tt_ = capi.Tree(cloud_h)
+                best_h = min(best_h, time.perf_counter() - t0)
+                tt_.close()
+            tb[name] = {"cloud_in_hbm_ms": best_d * 1e3, "cloud_on_host_ms": best_h * 1e3}
+            del d_c
+        ex["tree_build"] = {"workload": "pclmi_tree_create_dev / pclmi_tree_create, built on the GPU", **tb}
         t2.close()
     return ex
 
