@@ -1,6 +1,7 @@
 // api_icp.hip - C ABI: correspondences, rigid-transform estimation, transform, ICP.
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstring>
 #include <random>
 #include <vector>
@@ -511,6 +512,21 @@ int pclmi_debug_icp_ticks(pclmi_icp_ctx *c, unsigned long long out[4]) {
   PCLMI_HIP(hipMemcpyAsync(&h, c->state.p, sizeof(h), hipMemcpyDeviceToHost, s));
   PCLMI_HIP(hipStreamSynchronize(s));
   for (int i = 0; i < 4; ++i) out[i] = h.ticks[i];
+  return PCLMI_OK;
+}
+
+// the same for the walk stamps of a -DPCLMI_ICP_TICKS build (zeros otherwise)
+int pclmi_debug_icp_walk(pclmi_icp_ctx *c, unsigned long long out[8]) {
+  PCLMI_CHECK(c && out, PCLMI_ERR_INVALID, "NULL argument");
+  hipStream_t s = c->user_stream ? c->user_stream : c->stream;
+  IcpDevState h;
+  PCLMI_HIP(hipMemcpyAsync(&h, c->state.p, sizeof(h), hipMemcpyDeviceToHost, s));
+  PCLMI_HIP(hipStreamSynchronize(s));
+  for (int i = 0; i < 8; ++i) out[i] = h.walk[i];
+  h.walk[6] = h.walk[7] = 0;  // the launch-wide maxima start afresh
+  PCLMI_HIP(hipMemcpyAsync((char *)c->state.p + offsetof(IcpDevState, walk) + 6 * sizeof(unsigned long long), &h.walk[6],
+                           2 * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+  PCLMI_HIP(hipStreamSynchronize(s));
   return PCLMI_OK;
 }
 

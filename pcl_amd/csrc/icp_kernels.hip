@@ -348,6 +348,22 @@ __global__ __launch_bounds__(64 * ICP_WPB) __attribute__((amdgpu_waves_per_eu(8,
     for (int j = 0; j < 12; ++j) T.m[j] = st->T[j];
   }
   if (tail.st && blockIdx.x == 0 && threadIdx.x == 0) tail.st->ticks[0] = (unsigned long long)wall_clock64();
+#ifdef PCLMI_ICP_TICKS
+  const bool stamp = tail.st && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0;
+#define PCLMI_WALK_STAMP(i)                                                   \
+  do {                                                                        \
+    __builtin_amdgcn_s_waitcnt(0);                                            \
+    if (stamp) tail.st->walk[i] = (unsigned long long)wall_clock64();         \
+  } while (0)
+#else
+#define PCLMI_WALK_STAMP(i) \
+  do {                      \
+  } while (0)
+#endif
+  PCLMI_WALK_STAMP(0);
+#ifdef PCLMI_ICP_TICKS
+  const unsigned long long wave_t0 = (unsigned long long)wall_clock64();
+#endif
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
   const int per = (gridDim.x + 7) >> 3;
@@ -372,35 +388,44 @@ __global__ __launch_bounds__(64 * ICP_WPB) __attribute__((amdgpu_waves_per_eu(8,
     }
     const bool searchable = alive && finite3(p);
     if (!searchable) p.x = p.y = p.z = __builtin_nanf("");
+    PCLMI_WALK_STAMP(1);
     unsigned long long best;
     int bslot = 0;
-    if (LANE) {
-      float tau0 = __builtin_inff();
-      if (have_prev && searchable) {
-        const int j = nn_slot[slot];
-        if (j >= 0) {  // the previous neighbour is an indexed point: its distance bounds the new nearest one
-          const float4 o = rows[j];
-          tau0 = sq3(p.x - o.x, p.y - o.y, p.z - o.z);
-        }
+    float tau0 = __builtin_inff();
+    int start_leaf = 0;  // heap id of the previous neighbour's bucket: where the per-lane walk starts
+    if (have_prev && searchable) {
+      const int j = nn_slot[slot];
+      if (j >= 0) {  // the previous neighbour is an indexed point: its distance bounds the new nearest one
+        const float4 o = rows[j];
+        tau0 = sq3(p.x - o.x, p.y - o.y, p.z - o.z);
+        start_leaf = t.M + j / L;
       }
-      const int root = have_prev ? wave_common_root(t, p.x, p.y, p.z, searchable, tau0) : 1;
-      best = lane_nearest(t, p.x, p.y, p.z, searchable, tau0,
-                          reinterpret_cast<float(*)[64]>(far_lds + (size_t)wib * levels * 64), lane, root, bslot);
-    } else {
-      best = wave_nearest(t, p.x, p.y, p.z, searchable, lane);
     }
+    PCLMI_WALK_STAMP(2);
+    const int root = have_prev ? wave_common_root(t, p.x, p.y, p.z, searchable, tau0) : 1;
+    PCLMI_WALK_STAMP(3);
+    if (LANE) {
+      best = lane_nearest(t, p.x, p.y, p.z, searchable, tau0,
+                          reinterpret_cast<float(*)[64]>(far_lds + (size_t)wib * levels * 64), lane, root, bslot,
+                          start_leaf);
+    } else {
+      // wave-uniform walk below the common root; lanes without a previous neighbour (first step, or the point was
+      // not searchable then) have an infinite bound, which only keeps the root at 1
+      best = wave_nearest(t, p.x, p.y, p.z, searchable, lane, have_prev != 0, tau0, root, &bslot);
+    }
+    PCLMI_WALK_STAMP(4);
     if (alive) {
       const int idx = searchable ? (int)(unsigned int)(best & 0xffffffffull) : -1;
       const float d = searchable ? __uint_as_float((unsigned int)(best >> 32)) : __builtin_nanf("");
       nn_idx[slot] = idx;
-      if (LANE) nn_slot[slot] = searchable ? bslot : -1;
+      nn_slot[slot] = searchable ? bslot : -1;
       if (searchable) {
         dc = fminf(d, thr2f);  // icp.hpp:101
         prev = dist[slot];
         dist[slot] = dc;
         counted = true;
         if ((double)d < thr2) {  // strict, icp.hpp:93
-          q = LANE ? rows[bslot] : reinterpret_cast<const float4 *>(t.cloud)[idx];
+          q = rows[bslot];
           paired = true;
           if (EST) {
             m = tn_slot[bslot];
@@ -410,6 +435,15 @@ __global__ __launch_bounds__(64 * ICP_WPB) __attribute__((amdgpu_waves_per_eu(8,
       }
     }
   }
+  PCLMI_WALK_STAMP(5);
+#ifdef PCLMI_ICP_TICKS
+  if (tail.st && (threadIdx.x & 63) == 0) {  // latest wave start and longest wave, over the launch ([6], [7]: the
+    __builtin_amdgcn_s_waitcnt(0);           //  host clears them between launches)
+    const unsigned long long now = (unsigned long long)wall_clock64();
+    atomicMax(&tail.st->walk[6], wave_t0);
+    atomicMax(&tail.st->walk[7], now - wave_t0);
+  }
+#endif
   if constexpr (EST != 0) {
     // fp32 expressions widened on assignment, as the reference writes them (:186-188, :219)
     const double a = (double)__fsub_rn(__fmul_rn(m.z, p.y), __fmul_rn(m.y, p.z));
@@ -798,7 +832,7 @@ void launch_icp_step(const pclmi_tree *t, float4 *d_pts, size_t n, bool apply, c
   else
     hipLaunchKernelGGL((icp_step_kernel<false, 0>), dim3(blocks), dim3(64 * ICP_WPB), 0, s, t->view(), d_pts, (int)n,
                        apply ? 1 : 0, T, (float)thr2, thr2, d_nn, d_nn_slot, d_dist, origin[0], origin[1], origin[2],
-                       d_partials, (const IcpDevState *)st, 0, 0, tail, (const float4 *)nullptr,
+                       d_partials, (const IcpDevState *)st, 0, have_prev ? 1 : 0, tail, (const float4 *)nullptr,
                        (const unsigned char *)nullptr);
 }
 

@@ -259,6 +259,9 @@ struct IcpDevState {
   // wall_clock64() (100 MHz) of the last step launch: [0] workgroup 0 started, [1] last workgroup arrived,
   // [2] sums ready (after the exchange), [3] solve done.  Development aid (pclmi_debug_icp_ticks).
   unsigned long long ticks[4];
+  // -DPCLMI_ICP_TICKS builds only: stamps of wave 0 of the middle workgroup along its walk ([0] start, [1] point
+  // loaded, [2] start bound known, [3] common root found, [4] nearest found, [5] results stored, [6] sums in LDS)
+  unsigned long long walk[8];
 };
 // What the workgroup that finishes a step's reduction goes on to do (icp_kernels.hip icp_step_tail): group sums,
 // the launch's sums, the exchange with the other ranks (comm.world > 1), the solve (solve != 0, needs st).

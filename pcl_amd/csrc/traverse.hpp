@@ -221,12 +221,17 @@ __device__ __forceinline__ void expand_inner(LaneStack &st, const cgrp_ptr box2,
 
 // Wave-uniform 1-NN search: returns each lane's best 64-bit key (d2 bits << 32 | index) for the
 // lane's query; non-searchable lanes return the initial key (FLT_MAX, 0x7fffffff).
+// tau_known: the caller has an upper bound per lane (tau0, attained by an indexed point) and the node every lane's
+// ball lies under (root, e.g. wave_common_root); otherwise the bound comes from the per-lane pre-pass and the walk
+// starts at the tree's root.  best_slot (nullable): bucket slot of the result.
 __device__ __forceinline__ unsigned long long wave_nearest(const TreeView &t, float qx, float qy, float qz,
-                                                           bool searchable, int lane) {
+                                                           bool searchable, int lane, bool tau_known = false,
+                                                           float tau0 = 0.f, int root = 1, int *best_slot = nullptr) {
   unsigned long long best = make_key(3.402823466e+38f, 0x7fffffff);
-  float tau = searchable ? lane_bound<1>(t, qx, qy, qz) : -1.f;
+  int bslot = 0;
+  float tau = !searchable ? -1.f : tau_known ? tau0 : lane_bound<1>(t, qx, qy, qz);
   LaneStack st{0, 0, lane};
-  st.push(1);
+  st.push(tau_known ? root : 1);
   const cbox_ptr box = (cbox_ptr)t.box;
   const cgrp_ptr box2 = (cgrp_ptr)t.box;
   const cgrp_ptr leaf = (cgrp_ptr)t.leaf;
@@ -250,7 +255,10 @@ __device__ __forceinline__ unsigned long long wave_nearest(const TreeView &t, fl
                                 q2z - f2v{grp[g][8 + 2 * h], grp[g][9 + 2 * h]});
           const unsigned long long k0 = make_key(d2.x, __float_as_int(grp[g][12 + 2 * h]));
           const unsigned long long k1 = make_key(d2.y, __float_as_int(grp[g][13 + 2 * h]));
+          const int s0 = (node - M) * L + g * 4 + 2 * h;
+          bslot = k0 < best ? s0 : bslot;
           best = k0 < best ? k0 : best;
+          bslot = k1 < best ? s0 + 1 : bslot;
           best = k1 < best ? k1 : best;
         }
       }
@@ -259,6 +267,7 @@ __device__ __forceinline__ unsigned long long wave_nearest(const TreeView &t, fl
       expand_inner(st, box2, node, M, qx, qy, qz, tau);
     }
   }
+  if (best_slot) *best_slot = bslot;
   return best;
 }
 
@@ -320,12 +329,14 @@ __device__ __forceinline__ int wave_common_root(const TreeView &t, float qx, flo
 // The walk itself, shared by the 1-NN and the k-NN kernels.  leaf(leaf_number, tau) scans one bucket for
 // the calling lane and returns the lane's new bound (<= tau); round() runs once per outer round with the
 // whole wave converged (the k-NN kernel compacts its candidate buffer there).
+// start: the node a lane's walk begins at - `root`, or (lane_start_at_leaf) a bucket below it whose path up to the
+// root has its far[] entries filled in already.
 template <class LeafFn, class RoundFn>
 __device__ __forceinline__ void lane_traverse(const TreeView &t, float qx, float qy, float qz, bool searchable,
                                               float tau, float (*far)[64], int lane, int root, LeafFn leaf,
-                                              RoundFn round) {
+                                              RoundFn round, int start = 0) {
   const int M = t.M;
-  int node = root;
+  int node = start ? start : root;
   unsigned int trail = 0;  // bit l set: the node on the current path at level l is the second child visited
   bool active = searchable;
   const f2v q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
@@ -403,13 +414,49 @@ __device__ __forceinline__ void lane_traverse(const TreeView &t, float qx, float
   }
 }
 
+// Bottom-up start of a per-lane walk: the lane already knows a bucket that very likely holds its answer (ICP: the
+// bucket of the previous iteration's neighbour).  Instead of walking down to it from `root` - one DEPENDENT load per
+// two levels, which is what a converged ICP iteration spends its time on - the walk starts AT that bucket and the
+// far[] entry of every level on the way up (the box distance of the path's sibling at that level, what the descent
+// would have left behind) is computed from loads whose addresses are all known up front: four levels in flight at a
+// time.  leaf_node must lie under `root`.
+__device__ __forceinline__ void lane_start_at_leaf(const TreeView &t, float qx, float qy, float qz, bool use,
+                                                   int leaf_node, int root, float (*far)[64], int lane) {
+  int n = use ? leaf_node : root;
+  while (__any(n > root)) {
+    int id[4];
+    float4 a[4];
+    float2 b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      id[u] = n > root ? n : 0;  // 0: nothing left at this step for this lane
+      n = n > root ? n >> 1 : n;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (id[u]) {
+        const float *bp = t.box + (size_t)(id[u] ^ 1) * 8;  // the sibling's box
+        a[u] = *reinterpret_cast<const float4 *>(bp);
+        b[u] = *reinterpret_cast<const float2 *>(bp + 4);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (id[u]) far[31 - __clz(id[u])][lane] = box_dist(qx, qy, qz, a[u].x, a[u].y, a[u].z, a[u].w, b[u].x, b[u].y);
+    }
+  }
+}
+
+// start_leaf_node: heap id of a bucket to start the walk at (see lane_start_at_leaf), 0: start at `root`
 __device__ __forceinline__ unsigned long long lane_nearest(const TreeView &t, float qx, float qy, float qz,
                                                            bool searchable, float tau0, float (*far)[64], int lane,
-                                                           int root, int &best_slot) {
+                                                           int root, int &best_slot, int start_leaf_node = 0) {
   // root: node the walk starts (and ends) at - 1, or wave_common_root(); best_slot: bucket slot of the result
   unsigned long long best = make_key(3.402823466e+38f, 0x7fffffff);
   int bslot = 0;
   const f2v q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
+  const bool up = searchable && start_leaf_node > root;
+  if (__any(up)) lane_start_at_leaf(t, qx, qy, qz, up, start_leaf_node, root, far, lane);
   lane_traverse(
       t, qx, qy, qz, searchable, tau0, far, lane, root,
       [&](int leafno, float tau) {  // all 16 slots (padded slots are at distance +inf)
@@ -436,7 +483,7 @@ __device__ __forceinline__ unsigned long long lane_nearest(const TreeView &t, fl
         }
         return fminf(tau, __uint_as_float((unsigned int)(best >> 32)));
       },
-      [] {});
+      [] {}, up ? start_leaf_node : 0);
   best_slot = bslot;
   return best;
 }
