@@ -99,11 +99,23 @@ class IterativeClosestPoint : public Registration<PointSource, PointTarget> {
     // `output` already holds input[indices] (Registration::align); the library sets w = 1, applies the
     // guess (icp.hpp:60-66) and iterates
     const bool sharded = comm_ && pclmi_comm_size(comm_) > 1;
+    if (sharded && Base::update_visualizer_) {
+      PCL_ERROR("[pcl::%s::computeTransformation] a visualization callback sees the whole source every iteration: it "
+                "cannot be combined with setComm\n", getClassName().c_str());
+      return;
+    }
     if (sharded)
       for (size_t i = 0; i < aligned.size(); ++i) aligned[i] = std::numeric_limits<float>::quiet_NaN();
     const float *src_xyz = reinterpret_cast<const float *>(output.points.data());
+    ObserverState os{this, &output, {}, {}};
     const int rc =
-        loop == 1 ? pclmi_icp_align_point_to_plane(&p, tree_->getDeviceTree(), src_xyz, output.points.size(),
+        Base::update_visualizer_
+            ? pclmi_icp_align_observed(&p, tree_->getDeviceTree(), src_xyz, output.points.size(), sizeof(PointSource),
+                                       loop == 1 ? src_normals : nullptr, sizeof(PointSource),
+                                       loop == 1 ? tgt_normals : nullptr, Base::target_->points.size(),
+                                       sizeof(PointTarget), guess.isIdentity() ? nullptr : guess.data(), &observe, &os,
+                                       final_transformation_.data(), aligned.data(), &stats_)
+        : loop == 1 ? pclmi_icp_align_point_to_plane(&p, tree_->getDeviceTree(), src_xyz, output.points.size(),
                                                    sizeof(PointSource), src_normals, sizeof(PointSource), tgt_normals,
                                                    Base::target_->points.size(), sizeof(PointTarget),
                                                    guess.isIdentity() ? nullptr : guess.data(), comm_,
@@ -149,6 +161,24 @@ class IterativeClosestPoint : public Registration<PointSource, PointTarget> {
               "transform delta %g, fitness delta %g\n", getClassName().c_str(), stats_.iterations,
               stats_.last_correspondences, stats_.last_inliers, stats_.converged, stats_.transform_delta,
               stats_.fitness_delta);
+  }
+
+  // trampoline of the per-iteration observer: rebuilds the reference's callback arguments
+  struct ObserverState {
+    IterativeClosestPoint *self;
+    PointCloudSource *output;
+    std::vector<int> si, ti;
+  };
+  static void observe(void *user, int, const float *cloud, const int32_t *src_idx, const int32_t *tgt_idx, size_t n) {
+    ObserverState *o = static_cast<ObserverState *>(user);
+    for (size_t i = 0; i < o->output->points.size(); ++i) {
+      o->output->points[i].x = cloud[4 * i + 0];
+      o->output->points[i].y = cloud[4 * i + 1];
+      o->output->points[i].z = cloud[4 * i + 2];
+    }
+    o->si.assign(src_idx, src_idx + n);
+    o->ti.assign(tgt_idx, tgt_idx + n);
+    o->self->update_visualizer_(*o->output, o->si, *o->self->target_, o->ti);
   }
 
   pclmi_icp_stats stats_;

@@ -7,6 +7,7 @@
 #include <functional>
 #include <limits>
 #include <string>
+#include <vector>
 
 #include <pcl/common/matrix4.h>
 #include <pcl/console/print.h>
@@ -78,9 +79,19 @@ class Registration : public PCLBase<PointSource> {
     tree_->setPointRepresentation(point_representation_);
   }
 
-  // The fused device loop has no per-iteration host hook: visualisation callbacks are not supported.
-  template <typename FunctionSignature>
-  bool registerVisualizationCallback(std::function<FunctionSignature> &) { return false; }
+  /** \brief registration.h registerVisualizationCallback: the function is called after every iteration with the
+    * moved source, the source indices of the pairs the estimator was given, the target and the matching target
+    * indices (icp.hpp:182-183).  With a callback registered the device loop runs one iteration per launch and the
+    * cloud travels to the host after each (pclmi_icp_align_observed). */
+  typedef std::function<void(const pcl::PointCloud<PointSource> &, const std::vector<int> &,
+                             const pcl::PointCloud<PointTarget> &, const std::vector<int> &)> UpdateVisualizerFn;
+  bool registerVisualizationCallback(UpdateVisualizerFn &visualizerCallback) {
+    if (visualizerCallback) {
+      update_visualizer_ = visualizerCallback;
+      return true;
+    }
+    return false;
+  }
 
   // impl/registration.hpp:71-109
   double getFitnessScore(double max_range = std::numeric_limits<double>::max()) {
@@ -152,6 +163,7 @@ class Registration : public PCLBase<PointSource> {
   int min_number_correspondences_;
   TransformationEstimationPtr transformation_estimation_;
   PointRepresentationConstPtr point_representation_;
+  UpdateVisualizerFn update_visualizer_;
 };
 
 }  // namespace pcl

@@ -417,6 +417,23 @@ int pclmi_icp_align_point_to_plane(const pclmi_icp_params *p, const pclmi_tree *
                                    const float *tgt_normals, size_t n_tgt, size_t tn_stride_bytes, const float *guess,
                                    pclmi_comm *comm, float final_T[16], float *aligned, pclmi_icp_stats *stats);
 
+/* Per-iteration observer ---------------------------------------------------------------------
+ * Registration::registerVisualizationCallback (registration/include/pcl/registration/registration.h,
+ * update_visualizer_; called at impl/icp.hpp:182-183 after every iteration with the moved source, the pairs the
+ * estimator was given, and the target).  on_iteration receives: the iteration number (1-based), the source as it
+ * stands after this iteration's transform (n_src rows of x, y, z, 1 in the caller's row order), and the n_pairs
+ * (source row, target row) pairs in ascending source order - with the RANSAC step on, its inliers.  The device
+ * loop then runs one iteration per launch with a download in between: an observed align costs PCIe time per
+ * iteration; results are those of pclmi_icp_align / _point_to_plane (tgt_normals == NULL: the SVD estimator).
+ * One GPU only. */
+typedef void (*pclmi_icp_iteration_fn)(void *user, int iteration, const float *cloud, const int32_t *src_idx,
+                                       const int32_t *tgt_idx, size_t n_pairs);
+int pclmi_icp_align_observed(const pclmi_icp_params *p, const pclmi_tree *target, const float *src, size_t n_src,
+                             size_t stride_bytes, const float *src_normals, size_t sn_stride_bytes,
+                             const float *tgt_normals, size_t n_tgt, size_t tn_stride_bytes, const float *guess,
+                             pclmi_icp_iteration_fn on_iteration, void *user, float final_T[16], float *aligned,
+                             pclmi_icp_stats *stats);
+
 /* Multi-GPU exchange (one process per GPU on one node) -----------------------------------
  * The reference is single-process (no counterpart); this is the exchange step of the sharded ICP loop
  * (one all-reduce of the PCLMI_ICP_NSUMS fp64 moments per iteration) kept BELOW the C ABI, so that C++

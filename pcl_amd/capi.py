@@ -154,6 +154,9 @@ SIGNATURES = {
     "pclmi_icp_align_point_to_plane": (C.c_int, [C.POINTER(IcpParams), C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t,
                                                  C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, c_f32p,
                                                  C.c_void_p, c_f32p, C.c_void_p, C.POINTER(IcpStats)]),
+    "pclmi_icp_align_observed": (C.c_int, [C.POINTER(IcpParams), C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t,
+                                           C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, c_f32p,
+                                           C.c_void_p, C.c_void_p, c_f32p, C.c_void_p, C.POINTER(IcpStats)]),
     "pclmi_comm_begin": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_void_p]),
     "pclmi_comm_connect": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pclmi_comm_create_shm": (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]),
@@ -562,6 +565,40 @@ def icp_align_point_to_plane(target_tree, src, tgt_normals, params=None, guess=N
         0 if sn is None else sn.shape[1] * 4, tn.ctypes.data, len(tn), tn.shape[1] * 4,
         None if g is None else g.ctypes.data_as(c_f32p), None if comm is None else comm.h, T.ctypes.data_as(c_f32p),
         out.ctypes.data, C.byref(st))
+    if rc not in (0, 6):
+        _check(rc)
+    return rc, T.reshape(4, 4), out, st
+
+
+ITERATION_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                           C.c_size_t)
+
+
+def icp_align_observed(target_tree, src, on_iteration, params=None, guess=None, tgt_normals=None, src_normals=None):
+    """pclmi_icp_align_observed: on_iteration(iteration, cloud[n, 4], src_idx[m], tgt_idx[m]) after every iteration
+    (Registration::registerVisualizationCallback).  tgt_normals selects the point-to-plane estimator."""
+    lib = load_library()
+    s = _pts(src)
+    tn = None if tgt_normals is None else _pts(tgt_normals)
+    sn = None if src_normals is None else _pts(src_normals)
+    p = params or icp_default_params()
+    T = np.zeros(16, np.float32)
+    out = np.zeros((len(s), 4), np.float32)
+    st = IcpStats()
+    g = None if guess is None else np.ascontiguousarray(guess, np.float32).reshape(16)
+    n = len(s)
+
+    def tramp(_user, it, cloud, si, ti, m):
+        on_iteration(it, np.ctypeslib.as_array(cloud, shape=(n, 4)).copy(),
+                     np.ctypeslib.as_array(si, shape=(m,)).copy() if m else np.zeros(0, np.int32),
+                     np.ctypeslib.as_array(ti, shape=(m,)).copy() if m else np.zeros(0, np.int32))
+
+    cb = ITERATION_FN(tramp)
+    rc = lib.pclmi_icp_align_observed(
+        C.byref(p), target_tree.h, s.ctypes.data, n, s.shape[1] * 4, None if sn is None else sn.ctypes.data,
+        0 if sn is None else sn.shape[1] * 4, None if tn is None else tn.ctypes.data, 0 if tn is None else len(tn),
+        0 if tn is None else tn.shape[1] * 4, None if g is None else g.ctypes.data_as(c_f32p),
+        C.cast(cb, C.c_void_p), None, T.ctypes.data_as(c_f32p), out.ctypes.data, C.byref(st))
     if rc not in (0, 6):
         _check(rc)
     return rc, T.reshape(4, 4), out, st

@@ -818,11 +818,88 @@ struct PlaneArgs {
   size_t n_tgt, tn_stride;
 };
 
+// Per-iteration observer (Registration::registerVisualizationCallback, registration.h update_visualizer_, called at
+// icp.hpp:182-183): after every iteration the moved source and the pairs the estimator was given go to the host.
+struct Observer {
+  pclmi_icp_iteration_fn fn = nullptr;
+  void *user = nullptr;
+  DevBuf<float4> outb;
+  DevBuf<int> tgt_of_orig;
+  DevBuf<unsigned char> keep;
+  std::vector<float> cloud;
+  std::vector<int32_t> si, ti;
+
+  // moves the source by the transform that is still pending (so that the next step does not apply it again),
+  // downloads it in the caller's row order and calls the observer
+  int emit(pclmi_icp_ctx *c, int iteration) {
+    hipStream_t s = c->stream;
+    if (c->pending) {
+      launch_transform(c->pts.p, c->n, make_xf(c->T), s);
+      c->pending = false;
+    }
+    if (c->dev_mode) launch_transform_pending(c->pts.p, c->n, c->state.p, s);
+    if (!outb.p) RC(outb.alloc(c->n));
+    cloud.resize(c->n * 4);
+    launch_unpermute(c->pts.p, c->order.p, c->n, outb.p, s);
+    PCLMI_HIP(hipMemcpyAsync(cloud.data(), outb.p, c->n * sizeof(float4), hipMemcpyDeviceToHost, s));
+    PCLMI_HIP(hipStreamSynchronize(s));
+    fn(user, iteration, cloud.data(), si.data(), ti.data(), si.size());
+    return PCLMI_OK;
+  }
+  // pairs under the distance threshold of the last step, in source order (call BEFORE the new transform is applied)
+  int pairs_from_step(pclmi_icp_ctx *c) {
+    hipStream_t s = c->stream;
+    if (!keep.p) {
+      RC(keep.alloc(c->n));
+      RC(tgt_of_orig.alloc(c->n));
+    }
+    launch_corr_flags(c->nn.p, c->pts.p, (const float4 *)c->tree->d_cloud, c->order.p, c->n, c->last_thr2, tgt_of_orig.p,
+                      keep.p, s);
+    return pairs_from_flags(c, keep.p, tgt_of_orig.p);
+  }
+  int pairs_from_flags(pclmi_icp_ctx *c, const unsigned char *d_keep, const int *d_tgt) {
+    std::vector<unsigned char> hk(c->n);
+    std::vector<int32_t> ht(c->n);
+    PCLMI_HIP(hipMemcpyAsync(hk.data(), d_keep, c->n, hipMemcpyDeviceToHost, c->stream));
+    PCLMI_HIP(hipMemcpyAsync(ht.data(), d_tgt, c->n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    PCLMI_HIP(hipStreamSynchronize(c->stream));
+    si.clear();
+    ti.clear();
+    for (size_t i = 0; i < c->n; ++i)
+      if (hk[i]) {
+        si.push_back((int32_t)i);
+        ti.push_back(ht[i]);
+      }
+    return PCLMI_OK;
+  }
+  // the inliers of the RANSAC step: entries of the pair list whose flag is set
+  int pairs_from_inliers(pclmi_icp_ctx *c, const int *d_pair_src, const int *d_pair_tgt, const unsigned char *d_flags,
+                         size_t cnt) {
+    std::vector<unsigned char> hf(cnt);
+    std::vector<int32_t> hs(cnt), ht(cnt);
+    PCLMI_HIP(hipMemcpyAsync(hf.data(), d_flags, cnt, hipMemcpyDeviceToHost, c->stream));
+    PCLMI_HIP(hipMemcpyAsync(hs.data(), d_pair_src, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    PCLMI_HIP(hipMemcpyAsync(ht.data(), d_pair_tgt, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    PCLMI_HIP(hipStreamSynchronize(c->stream));
+    si.clear();
+    ti.clear();
+    for (size_t i = 0; i < cnt; ++i)
+      if (hf[i]) {
+        si.push_back(hs[i]);
+        ti.push_back(ht[i]);
+      }
+    return PCLMI_OK;
+  }
+};
+
 // Registration::align for both estimators, on one GPU or over the ranks of `comm`
 int align_core(const pclmi_icp_params *p, const pclmi_tree *target, const float *src, size_t n_src, size_t stride_bytes,
                const float *guess, pclmi_comm *comm, const PlaneArgs *plane, float final_T[16], float *aligned,
-               pclmi_icp_stats *stats) {
+               pclmi_icp_stats *stats, pclmi_icp_iteration_fn on_iteration = nullptr, void *user = nullptr) {
   PCLMI_CHECK(p && target && final_T, PCLMI_ERR_INVALID, "NULL argument");
+  Observer obs;
+  obs.fn = on_iteration;
+  obs.user = user;
   set_identity(final_T);
   if (stats) {
     std::memset(stats, 0, sizeof(*stats));
@@ -830,6 +907,8 @@ int align_core(const pclmi_icp_params *p, const pclmi_tree *target, const float 
   }
   PCLMI_CHECK(n_src > 0 && src, PCLMI_ERR_INVALID, "empty source cloud");
   const int world = comm ? pclmi_comm_size(comm) : 1;
+  PCLMI_CHECK(!on_iteration || world == 1, PCLMI_ERR_UNSUPPORTED,
+              "the per-iteration observer sees the whole source: it is not available for a sharded align");
   PCLMI_CHECK(p->ransac_iterations <= 0 || world == 1, PCLMI_ERR_UNSUPPORTED,
               "the RANSAC rejection step needs the global pair list: set ransac_iterations = 0 for a sharded align");
   pclmi_icp_ctx *c = nullptr;
@@ -850,12 +929,17 @@ int align_core(const pclmi_icp_params *p, const pclmi_tree *target, const float 
     std::memset(&st, 0, sizeof(st));
     set_identity(st.last_transform);
     int enqueued = 0;
-    const int chunk_max = world > 1 ? 16 : 8;
+    const int chunk_max = obs.fn ? 1 : world > 1 ? 16 : 8;  // an observer is called after every single iteration
     while (!rc) {
       const int chunk = std::max(1, std::min(chunk_max, p->max_iterations - enqueued));
+      const int before = st.iterations;
       if ((rc = pclmi_icp_run_dev(c, p->max_correspondence_distance, chunk, nullptr))) break;
       enqueued += chunk;
       rc = pclmi_icp_state(c, final_T, &st);
+      if (obs.fn && !rc && st.iterations > before) {
+        if ((rc = obs.pairs_from_step(c))) break;
+        if ((rc = obs.emit(c, st.iterations))) break;
+      }
       if (st.converged) break;
     }
     if (stats) *stats = st;
@@ -889,6 +973,11 @@ int align_core(const pclmi_icp_params *p, const pclmi_tree *target, const float 
         used = ninl;
         solve_sums = rsums;  // pair sums of the inliers only
       }
+      if (obs.fn) {  // the pairs the estimator is about to get (icp.hpp:130-149)
+        rc = ninl >= 0 ? obs.pairs_from_inliers(c, rs.pair_src.p, rs.pair_tgt.p, rs.flags.p, (size_t)cnt)
+                       : obs.pairs_from_flags(c, rs.keep.p, rs.tgt_of_orig.p);
+        if (rc) break;
+      }
       if (used < p->min_correspondences) {  // icp.hpp:153-159
         set_error("not enough correspondences after RANSAC (%lld < %d)", (long long)used, p->min_correspondences);
         rc = PCLMI_ERR_NOT_ENOUGH;
@@ -900,6 +989,7 @@ int align_core(const pclmi_icp_params *p, const pclmi_tree *target, const float 
     if ((rc = pclmi_icp_set_transform(c, T))) break;    // icp.hpp:174 (applied by the next step / end)
     mat4_mul_f32(T, final_T, final_T);                  // icp.hpp:177
     ++iters;
+    if (obs.fn && (rc = obs.emit(c, iters))) break;     // icp.hpp:182-183
     tdelta = 0.0;
     {
       float fs = 0.f;
@@ -946,6 +1036,17 @@ int pclmi_icp_align_point_to_plane(const pclmi_icp_params *p, const pclmi_tree *
   PCLMI_CHECK(tgt_normals, PCLMI_ERR_INVALID, "tgt_normals is NULL");
   const PlaneArgs pa{src_normals, sn_stride_bytes, tgt_normals, n_tgt, tn_stride_bytes};
   return align_core(p, target, src, n_src, stride_bytes, guess, comm, &pa, final_T, aligned, stats);
+}
+
+int pclmi_icp_align_observed(const pclmi_icp_params *p, const pclmi_tree *target, const float *src, size_t n_src,
+                             size_t stride_bytes, const float *src_normals, size_t sn_stride_bytes,
+                             const float *tgt_normals, size_t n_tgt, size_t tn_stride_bytes, const float *guess,
+                             pclmi_icp_iteration_fn on_iteration, void *user, float final_T[16], float *aligned,
+                             pclmi_icp_stats *stats) {
+  PCLMI_CHECK(on_iteration, PCLMI_ERR_INVALID, "on_iteration is NULL");
+  const PlaneArgs pa{src_normals, sn_stride_bytes, tgt_normals, n_tgt, tn_stride_bytes};
+  return align_core(p, target, src, n_src, stride_bytes, guess, nullptr, tgt_normals ? &pa : nullptr, final_T, aligned,
+                    stats, on_iteration, user);
 }
 
 // CorrespondenceRejectorSampleConsensus::getRemainingCorrespondences

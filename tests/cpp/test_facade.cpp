@@ -627,6 +627,43 @@ TEST(IterativeClosestPointGolden) {
   double worst = 0;
   for (size_t i = 0; i < moved.size(); ++i) worst = std::max(worst, double(std::sqrt(sqDist(moved[i], cloud_reg[i]))));
   EXPECT(worst < 1e-4);
+  // registerVisualizationCallback (registration.h; called at icp.hpp:182-183): every iteration hands over the moved
+  // source and the pairs the estimator was given; the result is the unobserved align's
+  {
+    IterativeClosestPoint<PointXYZ, PointXYZ> obs;
+    obs.setInputCloud(cloud_source.makeShared());
+    obs.setInputTarget(cloud_target.makeShared());
+    obs.setMaximumIterations(50);
+    obs.setTransformationEpsilon(1e-8);
+    obs.setMaxCorrespondenceDistance(0.05);
+    int calls = 0;
+    size_t last_pairs = 0;
+    bool sane = true;
+    IterativeClosestPoint<PointXYZ, PointXYZ>::UpdateVisualizerFn fn =
+        [&](const PointCloud<PointXYZ> &src, const std::vector<int> &si, const PointCloud<PointXYZ> &tgt,
+            const std::vector<int> &ti) {
+          ++calls;
+          last_pairs = si.size();
+          sane = sane && si.size() == ti.size() && src.size() == cloud_source.size() && tgt.size() == cloud_target.size();
+          for (size_t i = 0; i < si.size() && sane; ++i)
+            sane = si[i] >= 0 && si[i] < int(src.size()) && ti[i] >= 0 && ti[i] < int(tgt.size()) &&
+                   (i == 0 || si[i] > si[i - 1]);
+        };
+    EXPECT(obs.registerVisualizationCallback(fn));
+    IterativeClosestPoint<PointXYZ, PointXYZ>::UpdateVisualizerFn none;
+    EXPECT(!obs.registerVisualizationCallback(none));
+    PointCloud<PointXYZ> seen;
+    obs.align(seen);
+    EXPECT(obs.hasConverged() && sane);
+    EXPECT_EQ(calls, obs.getNumberOfIterations());
+    EXPECT(last_pairs > 3 && last_pairs <= cloud_source.size());
+    Matrix4f To = obs.getFinalTransformation();
+    for (int i = 0; i < 16; ++i) EXPECT(To.data()[i] == transformation.data()[i]);
+    obs.setRANSACIterations(0);
+    calls = 0;
+    obs.align(seen);
+    EXPECT(obs.hasConverged() && sane && calls == obs.getNumberOfIterations());
+  }
   // a guess + an index view + too strict a threshold
   IndicesPtr view(new std::vector<int>);
   for (int i = 0; i < 397; i += 2) view->push_back(i);

@@ -310,3 +310,39 @@ def test_rccl_all_reduce_between_the_library_kernels():
                        capture_output=True, text=True, timeout=110)
     print(r.stdout[-2000:], r.stderr[-3000:])
     assert r.returncode == 0 and "RCCL single-rank loop OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("ransac,plane", [(0, False), (1000, False), (0, True), (1000, True)])
+def test_observed_align_reports_every_iteration(capi, orc, ransac, plane):
+    """pclmi_icp_align_observed (Registration::registerVisualizationCallback, icp.hpp:182-183): one call per iteration
+    with the moved source and the pairs given to the estimator; the align itself is the unobserved one, bit for bit."""
+    tgt = surface_cloud(20000, 77)
+    T0 = rigid(1.5, (1, 0, 1), (0.3, 0.1, -0.2))
+    src = orc.transform(tgt[::3], np.linalg.inv(T0))
+    src[5] = np.nan  # never paired
+    tt = capi.Tree(tgt)
+    tn = capi.normals(tt, tgt, k=12, viewpoint=(0, 0, 1e4))[:, :3].copy() if plane else None
+    p = capi.icp_default_params()
+    p.max_iterations, p.max_correspondence_distance, p.ransac_iterations = 6, 2.0, ransac
+    p.ransac_outlier_threshold = 0.5
+    seen = []
+    rc, T, out, st = capi.icp_align_observed(tt, src, lambda it, cloud, si, ti: seen.append((it, cloud, si, ti)), p,
+                                             tgt_normals=tn)
+    if plane:
+        rc2, T2, out2, st2 = capi.icp_align_point_to_plane(tt, src, tn, p)
+    else:
+        rc2, T2, out2, st2 = capi.icp_align(tt, src, p)
+    assert rc == rc2 == 0 and st.iterations == st2.iterations == 6
+    assert np.array_equal(T, T2) and np.array_equal(out.view(np.int32), out2.view(np.int32))
+    assert [s[0] for s in seen] == [1, 2, 3, 4, 5, 6]
+    assert np.array_equal(seen[-1][1].view(np.int32), out.view(np.int32))  # the last report is the aligned cloud
+    for it, cloud, si, ti in seen:
+        assert len(si) == len(ti) > 3 and (np.diff(si) > 0).all() and 5 not in si
+        assert si.min() >= 0 and si.max() < len(src) and ti.min() >= 0 and ti.max() < len(tgt)
+    assert len(seen[-1][2]) == st.last_inliers
+    if ransac == 0:
+        # the reported pairs are the nearest neighbours of the cloud as it stood BEFORE this iteration's transform
+        prev = seen[-2][1][:, :3]
+        idx, d2 = tt.knn(np.nan_to_num(prev), 1)
+        keep = (d2[:, 0] < 4.0) & np.isfinite(prev).all(axis=1)
+        assert np.array_equal(np.flatnonzero(keep), seen[-1][2]) and np.array_equal(idx[keep, 0], seen[-1][3])
