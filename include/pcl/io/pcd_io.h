@@ -2,14 +2,16 @@
 // (io/include/pcl/io/pcd_io.h; header layout io/include/pcl/io/impl/pcd_io.hpp:72-121, the
 // fixtures' own headers test/bun0.pcd:1-10).  Host code only.
 //
-// Supported: DATA ascii and DATA binary, header versions .5 / .6 / 0.7 (COLUMNS or FIELDS, optional
-// SIZE / TYPE / COUNT / VIEWPOINT), any field list - the fields named x, y, z (F 4) are read into the
-// point, every other field is skipped.  DATA binary_compressed is reported as unsupported.
+// Supported: DATA ascii, DATA binary and DATA binary_compressed (io/src/pcd_io.cpp:1116-1193: two 32-bit sizes,
+// then the LZF-compressed field-major image of the cloud - all x, then all y ...; padding fields named "_" are not
+// stored), header versions .5 / .6 / 0.7 (COLUMNS or FIELDS, optional SIZE / TYPE / COUNT / VIEWPOINT), any field
+// list - the fields named x, y, z (F 4) are read into the point, every other field is skipped.
 // Writers emit the reference's v0.7 header with FIELDS x y z, 12 bytes per point in binary files,
 // exactly what PCDWriter produces for pcl::PointXYZ (impl/pcd_io.hpp:124-240,430-610).
 #ifndef PCLMI_FACADE_IO_PCD_IO_H_
 #define PCLMI_FACADE_IO_PCD_IO_H_
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -135,6 +137,79 @@ inline int readHeader(std::istream &f, PCDHeader &h) {
 }
 }  // namespace detail
 
+namespace detail {
+// LZF (Marc Lehmann's liblzf byte format, what pcl::lzfDecompress / lzfCompress read and write, io/src/lzf.cpp):
+// a control byte below 32 starts a literal run of ctrl + 1 bytes; otherwise it is a back reference of length
+// (ctrl >> 5) + 2 (a length code of 7 is extended by the next byte) at distance ((ctrl & 31) << 8 | next byte) + 1.
+// Returns the number of bytes produced, 0 on malformed input or when the output does not fit.
+inline size_t lzfDecompress(const unsigned char *in, size_t in_len, unsigned char *out, size_t out_len) {
+  size_t ip = 0, op = 0;
+  while (ip < in_len) {
+    const unsigned ctrl = in[ip++];
+    if (ctrl < 32) {
+      const size_t run = ctrl + 1;
+      if (ip + run > in_len || op + run > out_len) return 0;
+      std::memcpy(out + op, in + ip, run);
+      ip += run;
+      op += run;
+    } else {
+      size_t len = ctrl >> 5;
+      if (ip >= in_len) return 0;
+      if (len == 7) {
+        len += in[ip++];
+        if (ip >= in_len) return 0;
+      }
+      const size_t dist = ((static_cast<size_t>(ctrl & 31u)) << 8 | in[ip++]) + 1;
+      len += 2;
+      if (dist > op || op + len > out_len) return 0;
+      for (size_t i = 0; i < len; ++i, ++op) out[op] = out[op - dist];  // may overlap: byte by byte
+    }
+  }
+  return op;
+}
+
+// Greedy LZF compressor (3-byte hash, most recent occurrence).  out must hold in_len + in_len / 16 + 64 bytes.
+inline size_t lzfCompress(const unsigned char *in, size_t in_len, unsigned char *out) {
+  std::vector<std::uint32_t> table(1u << 16, 0xffffffffu);
+  size_t ip = 0, op = 0, lit = 0;  // lit: start of the pending literal run
+  auto flush_literals = [&](size_t upto) {
+    while (lit < upto) {
+      const size_t run = std::min<size_t>(32, upto - lit);
+      out[op++] = static_cast<unsigned char>(run - 1);
+      std::memcpy(out + op, in + lit, run);
+      op += run;
+      lit += run;
+    }
+  };
+  while (ip + 2 < in_len) {
+    const std::uint32_t v = static_cast<std::uint32_t>(in[ip]) << 16 | static_cast<std::uint32_t>(in[ip + 1]) << 8 | in[ip + 2];
+    const std::uint32_t hsh = ((v * 2654435761u) >> 16) & 0xffffu;
+    const std::uint32_t ref = table[hsh];
+    table[hsh] = static_cast<std::uint32_t>(ip);
+    if (ref != 0xffffffffu && ip - ref <= 8192 && in[ref] == in[ip] && in[ref + 1] == in[ip + 1] &&
+        in[ref + 2] == in[ip + 2]) {
+      size_t len = 3;
+      while (ip + len < in_len && len < 264 && in[ref + len] == in[ip + len]) ++len;
+      flush_literals(ip);
+      const size_t dist = ip - ref - 1, l = len - 2;
+      if (l < 7) {
+        out[op++] = static_cast<unsigned char>((l << 5) | (dist >> 8));
+      } else {
+        out[op++] = static_cast<unsigned char>((7u << 5) | (dist >> 8));
+        out[op++] = static_cast<unsigned char>(l - 7);
+      }
+      out[op++] = static_cast<unsigned char>(dist & 0xff);
+      ip += len;
+      lit = ip;
+    } else {
+      ++ip;
+    }
+  }
+  flush_literals(in_len);
+  return op;
+}
+}  // namespace detail
+
 /** \brief Load a PCD file into a cloud (io/include/pcl/io/pcd_io.h loadPCDFile).  Returns 0, or -1 on failure. */
 template <typename PointT>
 int loadPCDFile(const std::string &file_name, pcl::PointCloud<PointT> &cloud) {
@@ -169,7 +244,14 @@ int loadPCDFile(const std::string &file_name, pcl::PointCloud<PointT> &cloud) {
     const size_t remaining = end > static_cast<std::streamoff>(h.data_offset)
                                  ? static_cast<size_t>(end) - h.data_offset : 0;
     const size_t per_point = h.data == "binary" ? h.record : 2 * h.fields.size();
-    if (per_point == 0 || h.points > remaining / per_point + (h.data == "binary" ? 0 : 1)) {
+    if (h.data == "binary_compressed") {
+      // an LZF stream expands at most 264 / 3 = 88-fold (the longest back reference takes three bytes)
+      if (remaining < 8 || h.points > (remaining - 8) * 88 + 1) {
+        PCL_ERROR("[pcl::PCDReader::read] %s: header announces %zu points, the compressed payload cannot hold them.\n",
+                  file_name.c_str(), h.points);
+        return -1;
+      }
+    } else if (per_point == 0 || h.points > remaining / per_point + (h.data == "binary" ? 0 : 1)) {
       PCL_ERROR("[pcl::PCDReader::read] %s: header announces %zu points, the file holds fewer.\n", file_name.c_str(),
                 h.points);
       return -1;
@@ -240,9 +322,48 @@ int loadPCDFile(const std::string &file_name, pcl::PointCloud<PointT> &cloud) {
       std::memcpy(&p.y, rec + h.fields[fy].offset, 4);
       std::memcpy(&p.z, rec + h.fields[fz].offset, 4);
     }
+  } else if (h.data == "binary_compressed") {
+    // io/src/pcd_io.cpp:1116-1193
+    f.clear();
+    f.seekg(0, std::ios::end);
+    const size_t file_end = static_cast<size_t>(f.tellg());
+    f.seekg(static_cast<std::streamoff>(h.data_offset));
+    std::uint32_t sizes[2] = {0, 0};  // compressed, uncompressed
+    f.read(reinterpret_cast<char *>(sizes), 8);
+    if (f.gcount() != 8 || sizes[0] > file_end - h.data_offset - 8) {
+      PCL_ERROR("[pcl::PCDReader::read] %s: compressed payload is short.\n", file_name.c_str());
+      return -1;
+    }
+    // field-major layout: one block per field that is not padding
+    size_t stored = 0, off_x = 0, off_y = 0, off_z = 0;
+    for (size_t i = 0; i < h.fields.size(); ++i) {
+      const detail::PCDField &fd = h.fields[i];
+      if (fd.name == "_") continue;
+      if (static_cast<int>(i) == fx) off_x = stored;
+      if (static_cast<int>(i) == fy) off_y = stored;
+      if (static_cast<int>(i) == fz) off_z = stored;
+      stored += static_cast<size_t>(fd.size) * static_cast<size_t>(fd.count) * h.points;
+    }
+    if (stored != sizes[1]) {
+      PCL_ERROR("[pcl::PCDReader::read] %s: the header describes %zu bytes, the compressed block says %u.\n",
+                file_name.c_str(), stored, sizes[1]);
+      return -1;
+    }
+    std::vector<unsigned char> packed(sizes[0]), raw(stored ? stored : 1);
+    f.read(reinterpret_cast<char *>(packed.data()), static_cast<std::streamsize>(packed.size()));
+    if (static_cast<size_t>(f.gcount()) != packed.size() ||
+        detail::lzfDecompress(packed.data(), packed.size(), raw.data(), stored) != stored) {
+      PCL_ERROR("[pcl::PCDReader::read] Size of decompressed lzf data does not match value stored in PCD header\n");
+      return -1;
+    }
+    for (size_t i = 0; i < h.points; ++i) {
+      PointT &p = cloud.points[i];
+      std::memcpy(&p.x, raw.data() + off_x + 4 * i, 4);
+      std::memcpy(&p.y, raw.data() + off_y + 4 * i, 4);
+      std::memcpy(&p.z, raw.data() + off_z + 4 * i, 4);
+    }
   } else {
-    PCL_ERROR("[pcl::PCDReader::read] %s: DATA %s is not supported (ascii and binary are).\n", file_name.c_str(),
-              h.data.c_str());
+    PCL_ERROR("[pcl::PCDReader::read] %s: DATA %s is not supported.\n", file_name.c_str(), h.data.c_str());
     return -1;
   }
   for (size_t i = 0; i < cloud.points.size(); ++i) {
@@ -319,6 +440,40 @@ int savePCDFileBinary(const std::string &file_name, const pcl::PointCloud<PointT
     raw[3 * i + 2] = cloud.points[i].z;
   }
   f.write(reinterpret_cast<const char *>(raw.data()), static_cast<std::streamsize>(raw.size() * sizeof(float)));
+  return f.good() ? 0 : -1;
+}
+
+/** \brief pcl::io::savePCDFileBinaryCompressed (io/src/pcd_io.cpp writeBinaryCompressed): field-major image, LZF */
+template <typename PointT>
+int savePCDFileBinaryCompressed(const std::string &file_name, const pcl::PointCloud<PointT> &cloud) {
+  if (cloud.empty()) {
+    PCL_ERROR("[pcl::PCDWriter::writeBinaryCompressed] Input point cloud has no data!\n");
+    return -1;
+  }
+  const size_t n = cloud.points.size();
+  if (n * 12 > 0xffffffffull) {
+    PCL_ERROR("[pcl::PCDWriter::writeBinaryCompressed] cloud too large for the format's 32-bit sizes\n");
+    return -1;
+  }
+  std::ofstream f(file_name.c_str(), std::ios::binary);
+  if (!f) {
+    PCL_ERROR("[pcl::PCDWriter::writeBinaryCompressed] Could not open file for writing.\n");
+    return -1;
+  }
+  std::vector<float> soa(n * 3);
+  for (size_t i = 0; i < n; ++i) {
+    soa[i] = cloud.points[i].x;
+    soa[n + i] = cloud.points[i].y;
+    soa[2 * n + i] = cloud.points[i].z;
+  }
+  const size_t raw_bytes = soa.size() * sizeof(float);
+  std::vector<unsigned char> packed(raw_bytes + raw_bytes / 16 + 64);
+  const size_t packed_bytes = detail::lzfCompress(reinterpret_cast<const unsigned char *>(soa.data()), raw_bytes, packed.data());
+  const std::string hdr = detail::generateHeader(cloud) + "DATA binary_compressed\n";
+  const std::uint32_t sizes[2] = {static_cast<std::uint32_t>(packed_bytes), static_cast<std::uint32_t>(raw_bytes)};
+  f.write(hdr.data(), static_cast<std::streamsize>(hdr.size()));
+  f.write(reinterpret_cast<const char *>(sizes), 8);
+  f.write(reinterpret_cast<const char *>(packed.data()), static_cast<std::streamsize>(packed_bytes));
   return f.good() ? 0 : -1;
 }
 
