@@ -185,6 +185,7 @@ def main():
     verbose = rehearsal or os.environ.get("PCLMI_BENCH_VERBOSE") == "1"
     tstream = torch.cuda.Stream(device=dev)
     phase = {"name": "start"}
+    partial = {"out": None}  # the line as far as it has got: printed by rank 0's watchdog if a later part hangs
     if verbose or world > 1:
         # A stuck rank says where AND what is stuck: after PCLMI_BENCH_WATCHDOG seconds (default 240) of one phase the
         # watchdog prints whether the bench stream has drained (hipStreamQuery: "GPU busy" vs "GPU idle, host or
@@ -210,6 +211,10 @@ def main():
                           (rank, last, limit, drained, capi.load_library().pclmi_timing_pending()),
                           file=sys.stderr, flush=True)
                     faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+                    if rank == 0 and partial["out"] is not None:
+                        # the headline was measured: report it with what is missing rather than nothing
+                        partial["out"]["aborted_in_phase"] = last
+                        print(json.dumps(partial["out"]), flush=True)
                     os._exit(3)
 
         threading.Thread(target=watchdog, daemon=True).start()
@@ -320,14 +325,26 @@ def main():
                      "valu_issue_frac": pmc_valu_issue(pmc, kern_ms)},
     }
 
+    partial["out"] = out
+    # The side lines below never take the headline with them: a failure is recorded in the line, not raised.
     # ---- ICP iterations / s (configs[3]) -------------------------------------------------------
     if not args.no_icp:
         log("kNN done: %.3e queries/s; ICP next" % value)
-        out["icp"] = bench_icp(env)
+        try:
+            out["icp"] = bench_icp(env)
+        except Exception as e:  # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+            out["icp"] = {"error": repr(e)}
 
     # ---- extras: the other configurations of BASELINE.json as measured side lines ----------------
-    if not args.no_extras:
-        out["extras"] = bench_extras(env, tree, target, q_host, q, stream)
+    if not args.no_extras and "error" not in out.get("icp", {}):
+        try:
+            out["extras"] = bench_extras(env, tree, target, q_host, q, stream)
+        except Exception as e:  # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+            out["extras"] = {"error": repr(e)}
 
     # ---- CPU baseline (rank 0, N = 1 only) -----------------------------------------------------
     if world == 1 and not args.no_cpu:
@@ -358,8 +375,22 @@ def bench_icp(env):
         # shared-memory object named after this job (launcher pid + rendezvous port)
         log("pclmi_comm rendezvous")
         name = "bench_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
-        comm = capi.Comm.from_shm(rank, world, name)
-        comm.set_timeout(float(os.environ.get("PCLMI_COMM_TIMEOUT", "20")))
+        comm_error = None
+        try:
+            comm = capi.Comm.from_shm(rank, world, name)
+            comm.set_timeout(float(os.environ.get("PCLMI_COMM_TIMEOUT", "20")))
+        except Exception as e:  # noqa: BLE001  (e.g. the peers' memory cannot be mapped on this node)
+            comm_error = repr(e)
+            print("[bench rank %d] pclmi_comm unavailable: %s" % (rank, comm_error), file=sys.stderr, flush=True)
+        # every rank must take the same path: the mailbox exchange only if ALL ranks have it
+        have = torch.tensor([0.0 if comm is None else 1.0], dtype=torch.float64, device="cpu" if env["rehearsal"] else dev)
+        dist.all_reduce(have, op=dist.ReduceOp.MIN)
+        if float(have.item()) < 1.0:
+            if comm is not None:
+                comm.close()
+                comm = None
+            if env["rehearsal"]:
+                raise RuntimeError("pclmi_comm unavailable in the rehearsal: %s" % comm_error)
 
     def make_ctx():
         # every rank passes the whole source: it is Hilbert-ordered once and cut into contiguous runs
@@ -388,19 +419,22 @@ def bench_icp(env):
         return rc, dt, T_final, st, shard
 
     log("ICP clouds and tree ready, warm-up align")
-    rc, _, _, _, shard = run("fused")  # warm-up pass (allocations, first touch, peer mappings)
     exchange = "none (one GPU)" if world == 1 else "pclmi_comm: peer mailboxes, fused into the step kernel"
     res = None
-    if rc == 0:
-        log("ICP warm-up done, timed align")
-        rc, dt, T_final, st, shard = run("fused")  # the timed align carries no instrumentation
+    rc = -1
+    shard = 0
+    if world == 1 or comm is not None:
+        rc, _, _, _, shard = run("fused")  # warm-up pass (allocations, first touch, peer mappings)
         if rc == 0:
-            res = (max_over_ranks(dt), T_final, st)
+            log("ICP warm-up done, timed align")
+            rc, dt, T_final, st, shard = run("fused")  # the timed align carries no instrumentation
+            if rc == 0:
+                res = (max_over_ranks(dt), T_final, st)
     rccl = None
     if world > 1 and not env["rehearsal"]:
         log("ICP align with the exchange as an RCCL all-reduce")
         run("rccl")
-        rc2, dt2, T2, st2, _ = run("rccl")
+        rc2, dt2, T2, st2, shard = run("rccl")
         if rc2 == 0:
             rccl = (max_over_ranks(dt2), T2, st2)
     if res is None:  # the mailbox exchange timed out (reported, never silent): the RCCL line is the result

@@ -80,16 +80,20 @@ def icp_align_gpu_sharded(target_tree, src_shard, params, guess=None, group=None
     ctx = capi.IcpShard(target_tree, src_shard, guess)
     dev = torch.device("cuda", torch.cuda.current_device())
     sums = torch.zeros(capi.ICP_NSUMS, dtype=torch.float64, device=dev)
-    s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+    # the step, the collective and the download of the sums must be ordered on ONE stream: a caller's raw stream
+    # handle becomes torch's current stream for the duration of the loop
+    ext = torch.cuda.ExternalStream(stream, device=dev) if stream else None
+    with torch.cuda.stream(ext if ext is not None else torch.cuda.current_stream()):
+        s = torch.cuda.current_stream().cuda_stream
 
-    def step():
-        ctx.step_dev(params.max_correspondence_distance, sums.data_ptr(), s or None)
-        if not s:
-            torch.cuda.synchronize()  # the library's own stream was used: order it before the collective
-        return sums
+        def step():
+            ctx.step_dev(params.max_correspondence_distance, sums.data_ptr(), s or None)
+            if not s:
+                torch.cuda.synchronize()  # the library's own stream was used: order it before the collective
+            return sums
 
-    rc, T, it, ok, pairs = icp_align_sharded(step, ctx.set_transform, params, guess, group)
-    aligned = ctx.end()
+        rc, T, it, ok, pairs = icp_align_sharded(step, ctx.set_transform, params, guess, group)
+        aligned = ctx.end()
     return rc, T, aligned, it, ok, pairs
 
 
