@@ -45,7 +45,7 @@ int pclmi_normals_dev(const pclmi_tree *t, const float *d_q, size_t nq, size_t q
       PCLMI_CHECK(g.w, PCLMI_ERR_OOM, "no workspace");
       const int32_t *order = nullptr;
       RC(launch_morton_order(t, g.w, d_q, nq, qsf, nullptr, nullptr, s, &order));
-      RC(launch_knn_normals(t, d_q, nq, qsf, order, k_eff, vp, d_normals, s));
+      RC(launch_knn_normals(t, g.w, d_q, nq, qsf, order, k_eff, vp, d_normals, s));
       PCLMI_HIP(hipStreamSynchronize(s));
       return PCLMI_OK;
     }

@@ -37,6 +37,14 @@
 #ifndef PCLMI_IX32
 #define PCLMI_IX32 80
 #endif
+// keep the pre-pass list (see knn_union_ix_kernel); 0 = round-1 behaviour, for A/B runs
+#ifndef PCLMI_RETAIN
+#define PCLMI_RETAIN 1
+#endif
+// epilogue with one gather per buffered candidate (knn_finish); 0 = filter, then gather the survivors again
+#ifndef PCLMI_FINISH_ONE_GATHER
+#define PCLMI_FINISH_ONE_GATHER 1
+#endif
 #include "eig3.hpp"
 #include "pclmi_internal.h"
 #include "traverse.hpp"
@@ -44,12 +52,13 @@
 namespace pclmi {
 #ifdef PCLMI_STATS
 // development counters (make variant NAME=stats EXTRA=-DPCLMI_STATS): per-launch totals over all waves
-__device__ unsigned long long g_knn_stats[8];  // 0 leaves, 1 leaf groups with any pass, 2 chain executions,
-                                               // 3 compactions, 4 inner expansions, 6 waves
-extern "C" void pclmi_debug_knn_stats(unsigned long long out[8], int reset) {
-  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_knn_stats), sizeof(unsigned long long) * 8);
+__device__ unsigned long long g_knn_stats[16];  // 0 buckets scanned, 1 candidates some lane appended, 2 chain executions,
+                                                // 3 compactions, 4 inner expansions, 5 buckets popped, 6 waves,
+                                                // 8 / 9 / 10 clock64 ticks of pre-pass / walk / epilogue (per wave)
+extern "C" void pclmi_debug_knn_stats(unsigned long long out[16], int reset) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_knn_stats), sizeof(unsigned long long) * 16);
   if (reset) {
-    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_knn_stats), z, sizeof(z));
   }
 }
@@ -57,7 +66,11 @@ extern "C" void pclmi_debug_knn_stats(unsigned long long out[8], int reset) {
   do {                                                                    \
     if ((threadIdx.x & 63) == 0) atomicAdd(&g_knn_stats[i], (unsigned long long)(v)); \
   } while (0)
+#define PCLMI_TICK(var) const long long var = clock64()
 #else
+#define PCLMI_TICK(var) \
+  do {                  \
+  } while (0)
 #define PCLMI_STAT(i, v) \
   do {                   \
   } while (0)
@@ -160,13 +173,64 @@ __device__ __forceinline__ void knn_finish(unsigned int (*buf)[64], const float4
                                            int lane, int cnt, float tau, int k_out, int *__restrict__ out_idx,
                                            float *__restrict__ out_d2) {
   const float qx = lq.x, qy = lq.y, qz = lq.z;
+  unsigned long long key[K];
+  if constexpr (PCLMI_FINISH_ONE_GATHER && K >= 16) {
+  // ---- final: ONE gather per buffered candidate (K >= 16; below that the two-pass form is faster: 0.29 vs 0.26 ms
+  // per 1M queries at K = 2, 0.41 vs 0.39 at K = 8, but 0.609 vs 0.622 at K = 16, 1.34 vs 1.36 at K = 32).  All bucket slots of the lane's buffer are read into registers
+  // first, so the buffer's own LDS rows can take the survivors' (d2, index) keys (two rows per key) while the rows are
+  // gathered eight at a time; the keys are then read back - no second gather of the K survivors.  More than K
+  // survivors (distance ties at the bound; rare) put the slots back and take compact_index_buffer's tie handling.
+  static_assert(C / 2 >= K, "the buffer must hold K keys");
+  unsigned int id[C];
+#pragma unroll
+  for (int e = 0; e < C; ++e) id[e] = buf[e][lane];
+  int maxcnt = cnt;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) maxcnt = max(maxcnt, __shfl_xor(maxcnt, o));
+  int n = 0;
+#pragma unroll
+  for (int e0 = 0; e0 < C; e0 += 8) {
+    if (e0 < maxcnt) {
+      float4 p[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        p[u] = (e0 + u < C && e0 + u < cnt) ? cloud[id[e0 + u < C ? e0 + u : 0]] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float d = sq3(qx - p[u].x, qy - p[u].y, qz - p[u].z);
+        if (e0 + u < C && e0 + u < cnt && d <= tau) {
+          if (n < C / 2) {
+            buf[2 * n][lane] = __float_as_uint(d);
+            buf[2 * n + 1][lane] = __float_as_uint(p[u].w);  // external index
+          }
+          ++n;
+        }
+      }
+    }
+  }
+  if (__any(n > K)) {
+#pragma unroll
+    for (int e = 0; e < C; ++e) buf[e][lane] = id[e];
+    float dk[K];
+    unsigned int ik[K];
+    n = compact_index_buffer<K, C>(buf, cloud, qx, qy, qz, lane, cnt, tau, dk, ik, true);
+#pragma unroll
+    for (int j = 0; j < K; ++j) key[j] = j < n ? (((unsigned long long)__float_as_uint(dk[j]) << 32) | ik[j]) : ~0ull;
+  } else {
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const unsigned int dj = buf[2 * j][lane], ij = buf[2 * j + 1][lane];
+      key[j] = j < n ? (((unsigned long long)dj << 32) | ij) : ~0ull;
+    }
+  }
+  } else {
   float dk[K];
   unsigned int ik[K];
   // ---- final: filter with the exact k-th distance, sort the survivors by (d2, index)
   cnt = compact_index_buffer<K, C>(buf, cloud, qx, qy, qz, lane, cnt, tau, dk, ik, true);
-  unsigned long long key[K];
 #pragma unroll
   for (int j = 0; j < K; ++j) key[j] = j < cnt ? (((unsigned long long)__float_as_uint(dk[j]) << 32) | ik[j]) : ~0ull;
+  }
   sort_keys<K>(key);
   if (lq.alive) {
     int *oi = out_idx + (size_t)lq.qi * k_out;
@@ -282,11 +346,31 @@ __global__ __launch_bounds__(64 * WPB) void knn_union_ix_kernel(TreeView t, cons
   unsigned int(*buf)[64] = lds[threadIdx.x >> 6];
   const float4 *cloud = reinterpret_cast<const float4 *>(t.slot);  // bucket-slot rows (x, y, z, idx bits)
 
+  PCLMI_TICK(tick0);
+  float a[K];
+#if PCLMI_RETAIN
+  // The pre-pass list is KEPT: a[] starts as the K smallest distances of the lane's home buckets (real points the
+  // walk will meet again), not K copies of their K-th distance, so the bound tightens with the first outside
+  // candidate instead of after K of them.  When the walk reaches a home bucket the lane appends what is still within
+  // its bound but inserts nothing (those distances are in a[] already).
+  int home = -0x40000000;  // no bucket number is near it: lanes without a query have no home
+  if (lq.searchable) {
+#if PCLMI_NOPREPASS
+#pragma unroll
+    for (int j = 0; j < K; ++j) a[j] = 3.402823466e+38f;
+#else
+    lane_bound_list<K>(t, qx, qy, qz, a, home);
+#endif
+  } else {
+#pragma unroll
+    for (int j = 0; j < K; ++j) a[j] = -1.f;
+  }
+#else
   const float bound = lq.searchable ? lane_bound<K>(t, qx, qy, qz) : -1.f;
   asm volatile("" ::"v"(bound));
-  float a[K];
 #pragma unroll
   for (int j = 0; j < K; ++j) a[j] = bound;
+#endif
   int cnt = 0;
   float dk[K];
   unsigned int ik[K];
@@ -297,19 +381,42 @@ __global__ __launch_bounds__(64 * WPB) void knn_union_ix_kernel(TreeView t, cons
   const cgrp_ptr box2 = (cgrp_ptr)t.box;
   const cgrp_ptr leaf = (cgrp_ptr)t.leaf;
   const int M = t.M;
+  asm volatile("" ::"v"(a[K - 1]));
+  PCLMI_TICK(tick1);
 
-  while (st.sp > 0) {
-    const int node = st.pop();
-    if (node >= M) {
-      const f8v b = box[node];
+  // Two phases per round, so that the k-best list is only ever WRITTEN in straight-line code that every round runs
+  // (as one loop with a `continue` for pruned buckets the compiler keeps two copies of a[] and moves all K values
+  // across at every bucket): pop and expand until a bucket some lane still needs comes up, then scan that bucket.
+  for (;;) {
+    int node = 0;
+    bool found = false;
+    while (st.sp > 0) {
+      node = st.pop();
+      if (node >= M) {
+        PCLMI_STAT(5, 1);
+        const f8v b = box[node];
+        const float md = box_dist(qx, qy, qz, b[0], b[1], b[2], b[3], b[4], b[5]);
+        if (__any(md <= a[K - 1])) {
+          found = true;
+          break;
+        }
+      } else {
+        PCLMI_STAT(4, 1);
+        expand_inner(st, box2, node, M, qx, qy, qz, a[K - 1]);
+      }
+    }
+    if (!found) break;
+    {
       const cgrp_ptr rec = leaf + (size_t)(node - M) * G;
       f16v grp[G];
 #pragma unroll
       for (int g = 0; g < G; ++g) grp[g] = rec[g];
-      const float md = box_dist(qx, qy, qz, b[0], b[1], b[2], b[3], b[4], b[5]);
-      if (!__any(md <= a[K - 1])) continue;
       PCLMI_STAT(0, 1);
       const f2v q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
+#if PCLMI_RETAIN
+      const bool is_home = (unsigned int)(node - home) < (unsigned int)prepass_buckets<K>();
+      const unsigned long long homeb = __ballot(is_home);
+#endif
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         float dd[4];
@@ -325,6 +432,20 @@ __global__ __launch_bounds__(64 * WPB) void knn_union_ix_kernel(TreeView t, cons
         for (int j = 0; j < 4; ++j) {
           const float d = dd[j];
           const bool pass = d <= a[K - 1];
+#if PCLMI_RETAIN
+          const unsigned long long pb = __ballot(pass);
+          if (pb) {
+            PCLMI_STAT(1, 1);
+            if (pass) {
+              buf[cnt][lane] = (unsigned int)(node - M) * L + g * 4 + j;  // bucket slot
+              ++cnt;
+            }
+            if (pb & ~homeb) {  // some lane meets this point for the first time
+              PCLMI_STAT(2, 1);
+              list_insert<K>(a, is_home ? __builtin_inff() : d);
+            }
+          }
+#else
           if (__any(pass)) {
             PCLMI_STAT(2, 1);
             if (pass) {
@@ -333,23 +454,30 @@ __global__ __launch_bounds__(64 * WPB) void knn_union_ix_kernel(TreeView t, cons
             }
             list_insert<K>(a, d);
           }
+#endif
         }
         if (__any(cnt > C - 4)) {
           PCLMI_STAT(3, 1);
           cnt = compact_index_buffer<K, C>(buf, cloud, qx, qy, qz, lane, cnt, a[K - 1], dk, ik, false);
         }
       }
-    } else {
-      PCLMI_STAT(4, 1);
-      expand_inner(st, box2, node, M, qx, qy, qz, a[K - 1]);
     }
   }
   PCLMI_STAT(6, 1);
+  asm volatile("" ::"v"(a[K - 1]));
+  PCLMI_TICK(tick2);
 
   if constexpr (NRM)
     normals_finish<K, C>(buf, cloud, lq, lane, cnt, a[K - 1], k_out, vpx, vpy, vpz, reinterpret_cast<float4 *>(out_d2));
   else
     knn_finish<K, C>(buf, cloud, lq, lane, cnt, a[K - 1], k_out, out_idx, out_d2);
+#ifdef PCLMI_STATS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PCLMI_TICK(tick3);
+  PCLMI_STAT(8, tick1 - tick0);
+  PCLMI_STAT(9, tick2 - tick1);
+  PCLMI_STAT(10, tick3 - tick2);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -814,9 +942,12 @@ int launch_morton_order(const pclmi_tree *t, Workspace *w, const float *d_q, siz
 }
 
 // vp != nullptr: the fused surface-normal variant (d_d2 receives nq x 4 floats, d_idx is unused)
+// (Measured and dropped: the pre-pass as a kernel of its own at three times the occupancy, lists handed over through
+// HBM - 100 us for 1M queries on its own against the 40 us it adds to the fused kernel's 605.)
 template <int K, int C, int WPB>
-static void launch_union_ix(const pclmi_tree *t, const float *d_q, size_t nq, size_t qsf, const int32_t *order,
-                            int k_eff, int32_t *d_idx, float *d_d2, hipStream_t s, const float *vp = nullptr) {
+static int launch_union_ix(const pclmi_tree *t, Workspace *, const float *d_q, size_t nq, size_t qsf,
+                           const int32_t *order, int k_eff, int32_t *d_idx, float *d_d2, hipStream_t s,
+                           const float *vp = nullptr) {
   unsigned waves = (unsigned)((nq + 63) / 64);
   unsigned blocks = (waves + WPB - 1) / WPB;
   blocks = (blocks + 7) & ~7u;
@@ -826,6 +957,7 @@ static void launch_union_ix(const pclmi_tree *t, const float *d_q, size_t nq, si
   else
     hipLaunchKernelGGL((knn_union_ix_kernel<K, C, WPB, false>), dim3(blocks), dim3(64 * WPB), 0, s, t->view(), d_q,
                        (int)qsf, order, (int)nq, k_eff, d_idx, d_d2, 0.f, 0.f, 0.f);
+  return PCLMI_OK;
 }
 
 template <int K, int C>
@@ -874,28 +1006,30 @@ const char *knn_kernel_name(const pclmi_tree *t, size_t nq, int k_eff) {
 bool knn_normals_fused(int k_eff) { return k_eff >= 2 && k_eff <= 32; }
 
 // the fused search + plane fit (normals_finish) for 2 <= k_eff <= 32: d_out receives nq x (nx, ny, nz, curvature)
-int launch_knn_normals(const pclmi_tree *t, const float *d_q, size_t nq, size_t qsf, const int32_t *order, int k_eff,
-                       const float vp[3], float *d_out, hipStream_t s) {
+int launch_knn_normals(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, size_t qsf, const int32_t *order,
+                       int k_eff, const float vp[3], float *d_out, hipStream_t s) {
   if (nq == 0) return PCLMI_OK;
   PCLMI_CHECK(knn_normals_fused(k_eff), PCLMI_ERR_INVALID, "fused normals need 2 <= k <= 32 (got %d)", k_eff);
   PCLMI_CHECK(nq < (size_t)1 << 31, PCLMI_ERR_UNSUPPORTED, "more than 2^31-1 queries in one call");
   TimingScope ts(PCLMI_TIMER_KNN, s);
+  int rc = PCLMI_OK;
   if (knn_sparse(t, nq)) {
     if (k_eff <= 4) launch_lane_ix<4, 32>(t, d_q, nq, qsf, order, k_eff, nullptr, d_out, s, vp);
     else if (k_eff <= 8) launch_lane_ix<8, 32>(t, d_q, nq, qsf, order, k_eff, nullptr, d_out, s, vp);
     else if (k_eff <= 16) launch_lane_ix<16, 40>(t, d_q, nq, qsf, order, k_eff, nullptr, d_out, s, vp);
     else launch_lane_ix<32, 64>(t, d_q, nq, qsf, order, k_eff, nullptr, d_out, s, vp);
   } else if (k_eff <= 2) {
-    launch_union_ix<2, 16, 1>(t, d_q, nq, qsf, order, k_eff, nullptr, d_out, s, vp);
+    rc = launch_union_ix<2, 16, 1>(t, w, d_q, nq, qsf, order, k_eff, nullptr, d_out, s, vp);
   } else if (k_eff <= 4) {
-    launch_union_ix<4, 16, 1>(t, d_q, nq, qsf, order, k_eff, nullptr, d_out, s, vp);
+    rc = launch_union_ix<4, 16, 1>(t, w, d_q, nq, qsf, order, k_eff, nullptr, d_out, s, vp);
   } else if (k_eff <= 8) {
-    launch_union_ix<8, PCLMI_IX8, 1>(t, d_q, nq, qsf, order, k_eff, nullptr, d_out, s, vp);
+    rc = launch_union_ix<8, PCLMI_IX8, 1>(t, w, d_q, nq, qsf, order, k_eff, nullptr, d_out, s, vp);
   } else if (k_eff <= 16) {
-    launch_union_ix<16, PCLMI_IX16, 1>(t, d_q, nq, qsf, order, k_eff, nullptr, d_out, s, vp);
+    rc = launch_union_ix<16, PCLMI_IX16, 1>(t, w, d_q, nq, qsf, order, k_eff, nullptr, d_out, s, vp);
   } else {
-    launch_union_ix<32, PCLMI_IX32, 1>(t, d_q, nq, qsf, order, k_eff, nullptr, d_out, s, vp);
+    rc = launch_union_ix<32, PCLMI_IX32, 1>(t, w, d_q, nq, qsf, order, k_eff, nullptr, d_out, s, vp);
   }
+  if (rc) return rc;
   PCLMI_HIP(hipGetLastError());
   return PCLMI_OK;
 }
@@ -905,6 +1039,7 @@ int launch_knn(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, s
   if (nq == 0 || k_eff <= 0) return PCLMI_OK;
   PCLMI_CHECK(nq < (size_t)1 << 31, PCLMI_ERR_UNSUPPORTED, "more than 2^31-1 queries in one call");
   TimingScope ts(PCLMI_TIMER_KNN, s);
+  int rc = PCLMI_OK;
   if (k_eff == 1) {
     constexpr int WPB = 4;
     unsigned waves = (unsigned)((nq + 63) / 64);
@@ -932,22 +1067,23 @@ int launch_knn(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, s
     else if (k_eff <= 16) launch_lane_ix<16, 40>(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
     else launch_lane_ix<32, 64>(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
   } else if (k_eff <= 2) {
-    launch_union_ix<2, 16, 1>(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
+    rc = launch_union_ix<2, 16, 1>(t, w, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
   } else if (k_eff <= 4) {
-    launch_union_ix<4, 16, 1>(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
+    rc = launch_union_ix<4, 16, 1>(t, w, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
   } else if (k_eff <= 8) {
-    launch_union_ix<8, PCLMI_IX8, 1>(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
+    rc = launch_union_ix<8, PCLMI_IX8, 1>(t, w, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
   } else if (k_eff <= 16) {
-    launch_union_ix<16, PCLMI_IX16, 1>(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
+    rc = launch_union_ix<16, PCLMI_IX16, 1>(t, w, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
   } else if (k_eff <= 32) {
-    launch_union_ix<32, PCLMI_IX32, 1>(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
+    rc = launch_union_ix<32, PCLMI_IX32, 1>(t, w, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
   } else {
     size_t bytes = (size_t)k_eff * nq * sizeof(unsigned long long);
-    int rc = w->ensure_scratch(bytes);
+    rc = w->ensure_scratch(bytes);
     if (rc) return rc;
     hipLaunchKernelGGL(knn_heap_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, s, t->view(), d_q,
                        (int)qsf, order, (int)nq, k_eff, (unsigned long long *)w->scratch, d_idx, d_d2);
   }
+  if (rc) return rc;
   PCLMI_HIP(hipGetLastError());
   return PCLMI_OK;
 }

@@ -207,8 +207,8 @@ int launch_knn(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, s
                const int32_t *d_order, int k_eff, int32_t *d_idx, float *d_d2, hipStream_t s);
 // the search fused with the surface-normal plane fit (k-NN neighbourhoods with knn_normals_fused(k_eff))
 bool knn_normals_fused(int k_eff);
-int launch_knn_normals(const pclmi_tree *t, const float *d_q, size_t nq, size_t q_stride_f, const int32_t *d_order,
-                       int k_eff, const float vp[3], float *d_out, hipStream_t s);
+int launch_knn_normals(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, size_t q_stride_f,
+                       const int32_t *d_order, int k_eff, const float vp[3], float *d_out, hipStream_t s);
 
 
 // ---- k-NN entry-point plumbing (api_core.hip), shared by pclmi_knn_dev / _async / _noalloc ----

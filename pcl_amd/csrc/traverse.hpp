@@ -20,6 +20,12 @@ typedef const f16v __attribute__((address_space(4))) *cgrp_ptr;   // 64-byte lin
 #ifndef PCLMI_PREPASS_MUL
 #define PCLMI_PREPASS_MUL 4
 #endif
+#ifndef PCLMI_ASM_MIN
+#define PCLMI_ASM_MIN 1
+#endif
+#ifndef PCLMI_ASM_CHAIN
+#define PCLMI_ASM_CHAIN 1
+#endif
 constexpr int L = kLeafSize;
 constexpr int G = L / 4;
 
@@ -74,10 +80,23 @@ __device__ __forceinline__ unsigned long long make_key(float d, int i) {
 template <int K>
 __device__ __forceinline__ void list_insert(float (&a)[K], float d) {
   // a ascending.  new a[j] = median(a[j-1], a[j], d); new a[0] = min(a[0], d).
+#if PCLMI_ASM_CHAIN
+  // the same instructions with the destination TIED to a[j]: the list is updated in place, in descending j.  Left to
+  // itself the compiler gives the updated list registers of its own and copies all K values across at every bucket
+  // of the k-NN walk (twice: in and out), some 25 moves per bucket.
+#pragma unroll
+  for (int j = K - 1; j >= 1; --j) asm("v_med3_f32 %0, %1, %0, %2" : "+v"(a[j]) : "v"(a[j - 1]), "v"(d));
+#else
 #pragma unroll
   for (int j = K - 1; j >= 1; --j) a[j] = __builtin_amdgcn_fmed3f(a[j - 1], a[j], d);
-  // min as a median with -inf: no canonicalising v_max pair around it
+#endif
+#if PCLMI_ASM_MIN
+  // the compiler folds med3(-inf, a, d) into a minnum with a canonicalising v_max on either operand (3 instructions);
+  // the bare instruction returns the same value for every input the list sees (a NaN d leaves a[0] as it is)
+  asm("v_min_f32 %0, %0, %1" : "+v"(a[0]) : "v"(d));
+#else
   a[0] = __builtin_amdgcn_fmed3f(-__builtin_inff(), a[0], d);
+#endif
 }
 
 // wave-uniform stack kept in the lanes of one VGPR
@@ -100,6 +119,7 @@ struct LaneStack {
 struct LaneQuery {
   float x, y, z;
   int qi;
+  int slot;         // position in the sorted batch
   bool alive;       // lane maps to a query row
   bool searchable;  // ... and that query is finite
 };
@@ -116,6 +136,7 @@ __device__ __forceinline__ bool load_lane_query(const float *__restrict__ q, int
   const int slot = (blk * WPB + wib) * 64 + lane;
   if (__builtin_amdgcn_readfirstlane(slot) >= nq) return false;  // whole wave past the end
   o.alive = slot < nq;
+  o.slot = slot;
   o.qi = o.alive ? (order ? order[slot] : slot) : 0;
   o.x = o.y = o.z = __builtin_nanf("");  // dead lanes: every comparison is false
   if (o.alive) {
@@ -136,8 +157,16 @@ __device__ __forceinline__ bool load_lane_query(const float *__restrict__ q, int
 // sibling bucket with ordinary vector loads, and return the K-th smallest distance found.  This
 // is only an UPPER BOUND on the true K-th distance (FLT_MAX when fewer than K points were seen);
 // starting the union traversal with it prunes the far subtrees from the first step on.
+// lane_bound_list leaves the whole ascending list of the K smallest distances found in a[] and the first of the NB
+// sibling buckets scanned (prepass_buckets<K>() of them) in home - the union k-NN kernel keeps both, see there.
 template <int K>
-__device__ __forceinline__ float lane_bound(const TreeView &t, float qx, float qy, float qz) {
+__host__ __device__ constexpr int prepass_buckets() {
+  return (PCLMI_PREPASS_MUL * K / L) > 2 ? (PCLMI_PREPASS_MUL * K / L) : 2;
+}
+
+template <int K>
+__device__ __forceinline__ void lane_bound_list(const TreeView &t, float qx, float qy, float qz, float (&a)[K],
+                                                int &home) {
   const int M = t.M;
   int node = 1;
   while (node < M) {
@@ -147,12 +176,12 @@ __device__ __forceinline__ float lane_bound(const TreeView &t, float qx, float q
     const float m1 = box_dist(qx, qy, qz, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y);
     node = 2 * node + (m1 < m0 ? 1 : 0);
   }
-  float a[K];
 #pragma unroll
   for (int j = 0; j < K; ++j) a[j] = 3.402823466e+38f;
   // scan the NB sibling buckets around the one reached (>= 2K points when they are all full)
-  constexpr int NB = (PCLMI_PREPASS_MUL * K / L) > 2 ? (PCLMI_PREPASS_MUL * K / L) : 2;
+  constexpr int NB = prepass_buckets<K>();
   const int first = node & ~(NB - 1);
+  home = first;
 #pragma unroll 1
   for (int s = 0; s < NB; ++s) {
     const int bn = first + s;
@@ -167,6 +196,13 @@ __device__ __forceinline__ float lane_bound(const TreeView &t, float qx, float q
       list_insert<K>(a, sq3(qx - X.w, qy - Y.w, qz - Z.w));
     }
   }
+}
+
+template <int K>
+__device__ __forceinline__ float lane_bound(const TreeView &t, float qx, float qy, float qz) {
+  float a[K];
+  int home;
+  lane_bound_list<K>(t, qx, qy, qz, a, home);
   return a[K - 1];
 }
 

@@ -7,6 +7,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import numpy as np
 import torch
 from pcl_amd import capi
+if os.environ.get("PCLMI_LIB"):
+    capi.load_library(os.environ["PCLMI_LIB"])
 
 n = int(float(sys.argv[1])); nq = int(float(sys.argv[2])); k = int(sys.argv[3]); reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 pts = (np.random.default_rng(20260101).random((n, 3), dtype=np.float32) * 1024).astype(np.float32)
