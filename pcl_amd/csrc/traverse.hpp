@@ -23,6 +23,9 @@ typedef const f16v __attribute__((address_space(4))) *cgrp_ptr;   // 64-byte lin
 #ifndef PCLMI_ASM_MIN
 #define PCLMI_ASM_MIN 1
 #endif
+#ifndef PCLMI_PREPASS_DESCENT2
+#define PCLMI_PREPASS_DESCENT2 1
+#endif
 #ifndef PCLMI_ASM_CHAIN
 #define PCLMI_ASM_CHAIN 1
 #endif
@@ -169,6 +172,23 @@ __device__ __forceinline__ void lane_bound_list(const TreeView &t, float qx, flo
                                                 int &home) {
   const int M = t.M;
   int node = 1;
+#if PCLMI_PREPASS_DESCENT2
+  // two levels per dependent load (the four grandchildren boxes are two adjacent 64-byte lines), packed box distances:
+  // towards the nearest grandchild.  Any bucket near the query will do - the walk only wants a finite starting bound.
+  const f2v q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
+  while (2 * node + 1 < M) {
+    const float4 *b = reinterpret_cast<const float4 *>(t.box + (size_t)node * 32);
+    const float4 a0 = b[0], a1 = b[1], a2 = b[2], a3 = b[3], c0 = b[4], c1 = b[5], c2 = b[6], c3 = b[7];
+    const f2v m01 = box_dist_pk(q2x, q2y, q2z, f2v{a0.x, a2.x}, f2v{a0.y, a2.y}, f2v{a0.z, a2.z}, f2v{a0.w, a2.w},
+                                f2v{a1.x, a3.x}, f2v{a1.y, a3.y});
+    const f2v m23 = box_dist_pk(q2x, q2y, q2z, f2v{c0.x, c2.x}, f2v{c0.y, c2.y}, f2v{c0.z, c2.z}, f2v{c0.w, c2.w},
+                                f2v{c1.x, c3.x}, f2v{c1.y, c3.y});
+    const bool r01 = m01.y < m01.x, r23 = m23.y < m23.x;
+    const float lo01 = r01 ? m01.y : m01.x, lo23 = r23 ? m23.y : m23.x;
+    const bool right = lo23 < lo01;
+    node = 4 * node + (right ? 2 + (r23 ? 1 : 0) : (r01 ? 1 : 0));
+  }
+#endif
   while (node < M) {
     const float4 *b = reinterpret_cast<const float4 *>(t.box + (size_t)node * 16);
     const float4 b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
