@@ -521,6 +521,16 @@ int pclmi_tree_create(const float *xyz, size_t n, size_t stride_bytes, const int
       t->bb_lo[d] = ht.bb_lo[d];
       t->bb_hi[d] = ht.bb_hi[d];
     }
+    {
+      double vol = 0.0;
+      for (int i = 0; i < ht.M; ++i) {
+        const float *b = &ht.box[(size_t)(ht.M + i) * 8];
+        vol += (double)(b[3] - b[0]) * (double)(b[4] - b[1]) * (double)(b[5] - b[2]);
+      }
+      const double bbv = (double)(ht.bb_hi[0] - ht.bb_lo[0]) * (double)(ht.bb_hi[1] - ht.bb_lo[1]) *
+                         (double)(ht.bb_hi[2] - ht.bb_lo[2]);
+      t->fill = bbv > 0.0 ? (float)(vol / bbv) : 0.f;
+    }
     // AoS copy of the buckets for per-lane gathers: slot s = (x, y, z, idx bits)
     std::vector<float> slot((size_t)ht.M * kLeafSize * 4);
     for (size_t sl = 0; sl < (size_t)ht.M * kLeafSize; ++sl) {

@@ -339,7 +339,7 @@ __device__ __forceinline__ void normals_finish(unsigned int (*buf)[64], const fl
 #endif
 template <int K, int C, int WPB, bool NRM = false>
 __global__ __launch_bounds__(64 * WPB)
-    __attribute__((amdgpu_waves_per_eu(K == 16 ? PCLMI_WAVES16 : K <= 4 ? 7 : K == 8 ? 6 : 2))) void knn_union_ix_kernel(TreeView t, const float *__restrict__ q,
+    __attribute__((amdgpu_waves_per_eu(K == 16 ? PCLMI_WAVES16 : K <= 4 ? 7 : K == 8 ? 6 : K == 32 ? 2 : 1))) void knn_union_ix_kernel(TreeView t, const float *__restrict__ q,
                                                                  int q_stride_f, const int *__restrict__ order,
                                                                  int nq, int k_out, int *__restrict__ out_idx,
                                                                  float *__restrict__ out_d2, float vpx, float vpy,
@@ -762,6 +762,23 @@ __device__ __forceinline__ unsigned int morton_cell(const float *p, float lox, f
   return curve_index(ix, iy, iz) >> shift;
 }
 
+// "Tube" order for clouds that fill their bounding box (pclmi_tree::fill): the y-z plane is cut into gy x gz square
+// tubes along x whose cross-section is the side of a cube that holds one wavefront's 64 queries, the tubes are walked
+// boustrophedon (neighbouring tubes are face neighbours, odd tubes run backwards) and the queries of a tube are ordered
+// by x.  ANY 64 consecutive queries are then a slab of a tube, about a cube - whereas 64 consecutive queries along the
+// Hilbert curve are a chain of ~17 small cells of arbitrary shape.  Measured on the 1M x 1M uniform case, k = 16: the
+// union of a wavefront's search balls touches 37 buckets instead of 47.
+// key = tube << 10 | x bin (1024 bins, reversed in odd tubes)
+__device__ __forceinline__ unsigned int tube_key(const float *p, float lox, float loy, float loz, float sx, float sy,
+                                                 float sz, int gy, int gz) {
+  const float fx = (p[0] - lox) * sx, fy = (p[1] - loy) * sy, fz = (p[2] - loz) * sz;
+  const unsigned int xb = (unsigned int)fminf(fmaxf(fx, 0.f), 1023.f);  // NaN clamps to 0: order only affects speed
+  const unsigned int ty = (unsigned int)fminf(fmaxf(fy, 0.f), (float)(gy - 1));
+  const unsigned int tz = (unsigned int)fminf(fmaxf(fz, 0.f), (float)(gz - 1));
+  const unsigned int tube = tz * (unsigned int)gy + ((tz & 1u) ? (unsigned int)gy - 1u - ty : ty);
+  return (tube << 10) | ((tube & 1u) ? 1023u - xb : xb);
+}
+
 // Query ordering = counting sort by Morton cell.  Only coherence matters (the order inside a
 // cell is irrelevant and results never depend on it), so one histogram pass, one scan and one
 // scatter pass replace a full radix sort.
@@ -804,7 +821,7 @@ __global__ void cell_scatter_kernel(const unsigned int *__restrict__ cell, const
 constexpr int TILE_TPB = 1024;
 __global__ __launch_bounds__(TILE_TPB) void tile_count_kernel(const float *__restrict__ q, int q_stride_f, int nq, float lox,
                                                               float loy, float loz, float sx, float sy, float sz, int shift,
-                                                              int lo_bits, int nb_hi, int tile_size, int ntiles,
+                                                              int lo_bits, int nb_hi, int tile_size, int ntiles, int gy, int gz,
                                                               unsigned int *__restrict__ cell, unsigned int *__restrict__ rank,
                                                               unsigned int *__restrict__ tilehist) {
   extern __shared__ unsigned int lds_hist[];
@@ -814,7 +831,8 @@ __global__ __launch_bounds__(TILE_TPB) void tile_count_kernel(const float *__res
   const long long begin = (long long)tile * tile_size;
   const long long end = begin + tile_size < (long long)nq ? begin + tile_size : (long long)nq;
   for (long long i = begin + threadIdx.x; i < end; i += TILE_TPB) {
-    const unsigned int c = morton_cell(q + (size_t)i * q_stride_f, lox, loy, loz, sx, sy, sz, shift);
+    const unsigned int c = gy > 0 ? tube_key(q + (size_t)i * q_stride_f, lox, loy, loz, sx, sy, sz, gy, gz)
+                                  : morton_cell(q + (size_t)i * q_stride_f, lox, loy, loz, sx, sy, sz, shift);
     cell[i] = c;
     rank[i] = atomicAdd(&lds_hist[c >> lo_bits], 1u);
   }
@@ -894,8 +912,39 @@ int launch_morton_order(const pclmi_tree *t, Workspace *w, const float *d_q, siz
     return e && e[0] == 'a';
   }();
   const bool two_level = !stable && !atomic_order && nq >= 32768;
-  const int lo_bits = bits / 2, hi_bits = bits - lo_bits;
-  const int nb_hi = 1 << hi_bits, nb_lo = 1 << lo_bits;
+  int lo_bits = bits / 2, hi_bits = bits - lo_bits;
+  int nb_hi = 1 << hi_bits, nb_lo = 1 << lo_bits;
+  // tube order (see tube_key) when the indexed cloud fills its box; PCLMI_ORDER=tube / hilbert forces one
+  static const int order_env = [] {
+    const char *e = getenv("PCLMI_ORDER");
+    return !e ? 0 : (e[0] == 't' ? 1 : (e[0] == 'h' ? 2 : 0));
+  }();
+  int gy = 0, gz = 0;
+  float tube_sc[3] = {0.f, 0.f, 0.f};
+  if (two_level && !w->fixed && order_env != 2 && (order_env == 1 || t->fill >= 0.2f)) {
+    const double ex = (double)bb_hi[0] - bb_lo[0], ey = (double)bb_hi[1] - bb_lo[1], ez = (double)bb_hi[2] - bb_lo[2];
+    if (ex > 0.0 && ey > 0.0 && ez > 0.0) {
+      static const double tube_scale = [] {
+        const char *e = getenv("PCLMI_TUBE_SCALE");  // development knob
+        return e ? atof(e) : 1.0;
+      }();
+      const double side = tube_scale * cbrt(64.0 * ex * ey * ez / (double)nq);  // of a cube with one wavefront's queries
+      gy = (int)(ey / side + 0.5);
+      gz = (int)(ez / side + 0.5);
+      gy = gy < 1 ? 1 : gy;
+      gz = gz < 1 ? 1 : gz;
+      while ((long long)gy * gz > 8192) {  // counters of one tile live in LDS
+        gy = gy > 1 ? (gy + 1) / 2 : 1;
+        gz = gz > 1 ? (gz + 1) / 2 : 1;
+      }
+      tube_sc[0] = (float)(1024.0 / ex);
+      tube_sc[1] = (float)(gy / ey);
+      tube_sc[2] = (float)(gz / ez);
+      lo_bits = 10;
+      nb_lo = 1024;
+      nb_hi = gy * gz;
+    }
+  }
   int ntiles = (int)((nq + 4095) / 4096);
   ntiles = ntiles > 512 ? 512 : ntiles;
   const int tile_size = (int)((nq + ntiles - 1) / ntiles);
@@ -911,8 +960,9 @@ int launch_morton_order(const pclmi_tree *t, Workspace *w, const float *d_q, siz
   const unsigned grid = (unsigned)((nq + 255) / 256);
   if (two_level) {
     hipLaunchKernelGGL(tile_count_kernel, dim3(ntiles), dim3(TILE_TPB), (size_t)nb_hi * sizeof(unsigned int), s, d_q,
-                       (int)q_stride_f, (int)nq, bb_lo[0], bb_lo[1], bb_lo[2], sc[0], sc[1], sc[2], 30 - bits, lo_bits, nb_hi,
-                       tile_size, ntiles, w->keys_in, w->ranks, w->hist);
+                       (int)q_stride_f, (int)nq, bb_lo[0], bb_lo[1], bb_lo[2], gy ? tube_sc[0] : sc[0],
+                       gy ? tube_sc[1] : sc[1], gy ? tube_sc[2] : sc[2], 30 - bits, lo_bits, nb_hi, tile_size, ntiles, gy, gz,
+                       w->keys_in, w->ranks, w->hist);
     size_t tmp = w->cap_tmp;
     PCLMI_HIP(hipcub::DeviceScan::ExclusiveSum(w->sort_tmp, tmp, w->hist, w->hist, nb_hi * ntiles + 1, s));
     hipLaunchKernelGGL(tile_scatter_kernel, dim3(grid), dim3(256), 0, s, w->keys_in, w->ranks, (int)nq, lo_bits, tile_size,
@@ -1015,6 +1065,7 @@ const char *knn_kernel_name(const pclmi_tree *t, size_t nq, int k_eff) {
   if (k_eff <= 8) return "knn_union_ix_kernel<8," PCLMI_STR(PCLMI_IX8) ",1>";
   if (k_eff <= 16) return "knn_union_ix_kernel<16," PCLMI_STR(PCLMI_IX16) ",1>";
   if (k_eff <= 32) return "knn_union_ix_kernel<32," PCLMI_STR(PCLMI_IX32) ",1>";
+  if (k_eff <= 64 && !knn_sparse(t, nq)) return "knn_union_ix_kernel<64,128,1>";
   return "knn_heap_kernel";
 }
 
@@ -1091,6 +1142,9 @@ int launch_knn(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, s
     rc = launch_union_ix<16, PCLMI_IX16, 1>(t, w, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
   } else if (k_eff <= 32) {
     rc = launch_union_ix<32, PCLMI_IX32, 1>(t, w, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
+  } else if (k_eff <= 64 && !knn_sparse(t, nq)) {
+    // the reference's own tests search with k = 64 (test/test_search.cpp:624-631): same kernel, one wave per SIMD
+    rc = launch_union_ix<64, 128, 1>(t, w, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
   } else {
     size_t bytes = (size_t)k_eff * nq * sizeof(unsigned long long);
     rc = w->ensure_scratch(bytes);

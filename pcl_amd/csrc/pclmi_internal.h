@@ -104,6 +104,9 @@ struct pclmi_tree {
   float *d_slot = nullptr;   // [M * L][4] (x, y, z, idx bits) in bucket order
   float *d_cloud = nullptr;  // [rows][4] copy of the original cloud (x, y, z, 1) for ICP gathers
   float bb_lo[3] = {0, 0, 0}, bb_hi[3] = {0, 0, 0};
+  // volume of the buckets' tight boxes over the volume of the bounding box: ~0.5 for a cloud that fills its box,
+  // ~0 for a surface scan.  Only steers the choice of the query order (launch_morton_order); never results.
+  float fill = 0.f;
   hipStream_t stream = nullptr;
   // workspace pool (const search calls are re-entrant: each takes a workspace)
   mutable std::mutex mu;
