@@ -899,10 +899,12 @@ int launch_morton_order(const pclmi_tree *t, Workspace *w, const float *d_q, siz
   if (!bb_hi) bb_hi = t->bb_hi;
   *d_order = nullptr;
   if (nq <= 64) return PCLMI_OK;  // a single wave: order is irrelevant
-  // cells: about 4 queries per cell, 2..8 bits per axis
+  // cells: one query per cell or fewer (measured on the 1M-point surface cloud, k = 16 normals: 4 queries per cell
+  // 0.597 ms, 0.5 per cell 0.565 ms, 0.06 per cell 0.578 ms; on the uniform cloud the three are equal), 2..8 bits per axis
   int lg = 0;
   while (((size_t)1 << lg) < nq) ++lg;
-  int bits = ((lg - 2) / 3) * 3;
+  int bits = ((lg + 1) / 3) * 3;
+  if (w->fixed) bits = ((lg - 2) / 3) * 3;  // the allocation-free entry point's histogram space is sized for 4 per cell
   bits = bits < 6 ? 6 : (bits > 24 ? 24 : bits);
   if (const char *e = getenv("PCLMI_CELL_BITS")) bits = atoi(e);  // development override
   const size_t nbins = (size_t)1 << bits;
