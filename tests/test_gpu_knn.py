@@ -77,13 +77,13 @@ def test_grid_ties(capi, orc, k):
 
 @pytest.mark.parametrize("k", [2, 3, 4, 5, 8, 10, 16, 20, 32])
 def test_sparse_batches_take_the_per_lane_kernel(capi, orc, k):
-    """Fewer than a quarter as many queries as target points: knn_lane_ix_kernel (each lane walks for itself).  The
+    """Fewer than a sixth as many queries as target points: knn_lane_ix_kernel (each lane walks for itself).  The
     same bars as the union kernel: ties on a grid, duplicates beyond a bucket, NaN queries, a ragged last wave - and
     both kernels must agree on one batch (PCLMI_KNN is read once per process, so the batch sizes pick the kernels)."""
     pts = util.grid_cloud()  # 1331 points, many exactly-equal distances
-    q = np.concatenate([pts[::11], np.array([[0.01, 0.01, 0.01], [0, 0, 0], [0.05, 0.05, 0.05]], np.float32),
+    q = np.concatenate([pts[::13], np.array([[0.01, 0.01, 0.01], [0, 0, 0], [0.05, 0.05, 0.05]], np.float32),
                         pts[:100] + np.float32(0.05)])
-    assert len(q) * 4 < len(pts)
+    assert len(q) * 6 < len(pts)
     _check(capi, orc, pts, q, k)
     rng = np.random.default_rng(61)
     base = rng.random((60, 3), dtype=np.float32)
@@ -98,11 +98,11 @@ def test_sparse_batches_take_the_per_lane_kernel(capi, orc, k):
     assert (gi[~good] == -1).all() and np.isnan(gd[~good]).all()
     big = util.uniform_cloud(120_000, 62, 0, 100)
     tb = capi.Tree(big)
-    sparse = util.uniform_cloud(20_001, 63, 0, 100)
-    dense = np.concatenate([sparse, util.uniform_cloud(20_000, 64, 0, 100)])  # 40 001 * 4 > 120 000: union kernel
+    sparse = util.uniform_cloud(15_001, 63, 0, 100)   # 15 001 * 6 < 120 000: per-lane kernel
+    dense = np.concatenate([sparse, util.uniform_cloud(20_000, 64, 0, 100)])  # 35 001 * 6 > 120 000: union kernel
     si, sd = tb.knn(sparse, k)
     di, dd = tb.knn(dense, k)
-    assert np.array_equal(si, di[:20_001]) and np.array_equal(sd.view(np.int32), dd[:20_001].view(np.int32))
+    assert np.array_equal(si, di[:15_001]) and np.array_equal(sd.view(np.int32), dd[:15_001].view(np.int32))
 
 
 def test_duplicates_and_tiny_clouds(capi, orc):
