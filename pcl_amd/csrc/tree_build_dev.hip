@@ -212,21 +212,21 @@ __global__ void root_copy_kernel(float *__restrict__ box) {
   if (threadIdx.x < 8) box[threadIdx.x] = box[8 + threadIdx.x];  // id 0 is unused: a stray read sees the root box
 }
 
-// sum of the buckets' box volumes (one workgroup; a statistic, not a result: see pclmi_tree::fill)
-__global__ __launch_bounds__(1024) void leaf_volume_kernel(const float *__restrict__ box, int M, float *__restrict__ out) {
-  __shared__ double part[1024];
+// sum of the buckets' box volumes (a statistic, not a result: see pclmi_tree::fill)
+__global__ __launch_bounds__(256) void leaf_volume_kernel(const float *__restrict__ box, int M, double *__restrict__ out) {
+  __shared__ double part[256];
   double v = 0.0;
-  for (int i = threadIdx.x; i < M; i += 1024) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < M; i += gridDim.x * 256) {
     const float *b = box + (size_t)(M + i) * 8;
     v += (double)(b[3] - b[0]) * (double)(b[4] - b[1]) * (double)(b[5] - b[2]);
   }
   part[threadIdx.x] = v;
   __syncthreads();
-  for (int o = 512; o > 0; o >>= 1) {
+  for (int o = 128; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[0] = (float)part[0];
+  if (threadIdx.x == 0) atomicAdd(out, part[0]);
 }
 
 inline unsigned grid_for(size_t n) { return (unsigned)((n + 255) / 256); }
@@ -353,13 +353,16 @@ int build_device_tree(pclmi_tree *t, const float *d_xyz, size_t n_rows, size_t s
   hipLaunchKernelGGL(leaves_fill_kernel, dim3(grid_for((size_t)M * L_)), dim3(256), 0, s, M, (const int *)begin,
                      (const int *)end, (const int *)cur[3], (const float4 *)pk.p, t->d_leaf, (float4 *)t->d_slot);
   hipLaunchKernelGGL(root_copy_kernel, dim3(1), dim3(64), 0, s, t->d_box);
-  DevBuf<float> vol;
+  DevBuf<double> vol;
   RC(vol.alloc(1));
-  hipLaunchKernelGGL(leaf_volume_kernel, dim3(1), dim3(1024), 0, s, (const float *)t->d_box, M, vol.p);
+  PCLMI_HIP(hipMemsetAsync(vol.p, 0, sizeof(double), s));
+  hipLaunchKernelGGL(leaf_volume_kernel, dim3((unsigned)((M + 1023) / 1024 < 256 ? (M + 1023) / 1024 : 256)), dim3(256), 0,
+                     s, (const float *)t->d_box, M, vol.p);
   PCLMI_HIP(hipGetLastError());
-  float root[8], h_vol = 0.f;
+  float root[8];
+  double h_vol = 0.0;
   PCLMI_HIP(hipMemcpyAsync(root, t->d_box + 8, sizeof(root), hipMemcpyDeviceToHost, s));
-  PCLMI_HIP(hipMemcpyAsync(&h_vol, vol.p, sizeof(float), hipMemcpyDeviceToHost, s));
+  PCLMI_HIP(hipMemcpyAsync(&h_vol, vol.p, sizeof(double), hipMemcpyDeviceToHost, s));
   PCLMI_HIP(hipStreamSynchronize(s));
   for (int d = 0; d < 3; ++d) {
     t->bb_lo[d] = root[d];
