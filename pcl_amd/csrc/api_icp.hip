@@ -4,6 +4,7 @@
 #include <cstddef>
 #include <cstring>
 #include <random>
+#include <unordered_map>
 #include <vector>
 
 #include "pclmi_internal.h"
@@ -633,8 +634,18 @@ struct RansacDev {
   DevBuf<unsigned int> count;
   DevBuf<float4> six;
   DevBuf<double> partials, sums;
+  DevBuf<RansacRng> rng;
+  DevBuf<RansacTrial> trials;
+  DevBuf<int> shuf;  // shuffled_indices_ (sac_model.h)
+  size_t cap_shuf = 0;
   int init(size_t n) {
+    if (n > cap_shuf) {
+      RC(shuf.alloc(n));
+      cap_shuf = n;
+    }
     if (count.p) return PCLMI_OK;
+    RC(rng.alloc(1));
+    RC(trials.alloc(kRansacBatch));
     RC(count.alloc(1));
     RC(six.alloc(6));
     RC(partials.alloc((size_t)pair_reduce_blocks(n) * PCLMI_ICP_NSUMS));
@@ -670,81 +681,61 @@ int ransac_core(RansacDev &rd, const float4 *src, const int *sidx, const float4 
   sthr /= 3.0;
   sthr *= sthr;
 
-  std::mt19937 gen(12345u);  // boost::mt19937 seed 12345 (sac_model.h:95); rnd() == gen() >> 1
-  std::vector<int> shuf(cnt);
-  for (int i = 0; i < cnt; ++i) shuf[i] = i;
+  // The trials, in batches (icp_kernels.hip "RANSAC trials in batches"): the generator (boost::mt19937, seed 12345,
+  // sac_model.h:95; rnd() == gen() >> 1), the index shuffle and isSampleGood run on the device, the three-point models
+  // of a batch are fitted in parallel and ONE pass over the pairs counts all their inliers; the host consumes the
+  // trials in order under the reference's stopping rule (ransac.hpp:71-121).  One round trip per batch instead of two
+  // per trial - with few inliers (a first ICP iteration) the reference's rule asks for hundreds of trials.
+  launch_ransac_seed(rd.rng.p, 12345u, s);
+  launch_iota(rd.shuf.p, (size_t)cnt, s);
   const double thresh = inlier_threshold * inlier_threshold;
   int iterations = 0, best = -INT32_MAX;
   double k = 1.0;
   unsigned skipped = 0;
   const unsigned max_skip = (unsigned)std::min<long long>((long long)max_iterations * 10, 0xffffffffll);
-  bool have = false;
-  float4 h6[6];
-  while (iterations < k && skipped < max_skip) {
-    bool good = false;
-    int sel[3] = {0, 0, 0};
-    for (unsigned iter = 0; iter < 1000u && !good; ++iter) {  // max_sample_checks_ (sac_model.h:470)
-      for (int i = 0; i < 3; ++i) {
-        const uint32_t r = (uint32_t)gen() >> 1;
-        std::swap(shuf[i], shuf[i + (int)(r % (uint32_t)(cnt - i))]);  // drawIndexSample (:401-412)
-      }
-      for (int i = 0; i < 3; ++i) sel[i] = shuf[i];
-      launch_gather_points(src, sidx, tgt, tidx, sel, rd.six.p, s);
-      PCLMI_HIP(hipMemcpyAsync(h6, rd.six.p, sizeof(h6), hipMemcpyDeviceToHost, s));
-      PCLMI_HIP(hipStreamSynchronize(s));
-      auto sq = [](const float4 &u, const float4 &v) {
-        const float dx = u.x - v.x, dy = u.y - v.y, dz = u.z - v.z;
-        return dx * dx + dy * dy + dz * dz;
-      };
-      good = (double)sq(h6[2], h6[0]) > sthr && (double)sq(h6[4], h6[0]) > sthr &&
-             (double)sq(h6[4], h6[2]) > sthr;  // isSampleGood (sac_model_registration.hpp:47-60)
-    }
-    if (!good) break;
-    // three-point rigid fit (estimateRigidTransformationSVD, sac_model_registration.hpp:257-302)
-    double sm[PCLMI_ICP_NSUMS] = {0};
-    const double o[3] = {h6[1].x, h6[1].y, h6[1].z};
-    for (int i = 0; i < 3; ++i) {
-      const double sx = h6[2 * i].x - o[0], sy = h6[2 * i].y - o[1], sz = h6[2 * i].z - o[2];
-      const double tx = h6[2 * i + 1].x - o[0], ty = h6[2 * i + 1].y - o[1], tz = h6[2 * i + 1].z - o[2];
-      sm[0] += 1;
-      sm[1] += sx; sm[2] += sy; sm[3] += sz;
-      sm[4] += tx; sm[5] += ty; sm[6] += tz;
-      sm[7] += sx * tx; sm[8] += sx * ty; sm[9] += sx * tz;
-      sm[10] += sy * tx; sm[11] += sy * ty; sm[12] += sy * tz;
-      sm[13] += sz * tx; sm[14] += sz * ty; sm[15] += sz * tz;
-      sm[18] += 1;
-      sm[19] += o[0]; sm[20] += o[1]; sm[21] += o[2];
-    }
-    float T[16];
-    if (solve_rigid_from_sums(sm, T) != PCLMI_OK) {
-      ++skipped;
-      continue;
-    }
-    unsigned int inl = 0;
-    launch_count_within(src, sidx, tgt, tidx, cnt, make_xf(T), thresh, rd.count.p, nullptr, s);
-    PCLMI_HIP(hipMemcpyAsync(&inl, rd.count.p, 4, hipMemcpyDeviceToHost, s));
+  bool have = false, stop = false;
+  RansacTrial ht[kRansacBatch];
+  int batch = 4;  // a converged ICP iteration needs one or two trials
+  while (!stop && iterations < k && skipped < max_skip) {
+    launch_ransac_draw(rd.rng.p, rd.shuf.p, cnt, src, sidx, tgt, tidx, sthr, batch, rd.trials.p, s);
+    launch_count_within_batch(src, sidx, tgt, tidx, (size_t)cnt, thresh, batch, rd.trials.p, s);
+    PCLMI_HIP(hipMemcpyAsync(ht, rd.trials.p, (size_t)batch * sizeof(RansacTrial), hipMemcpyDeviceToHost, s));
     PCLMI_HIP(hipStreamSynchronize(s));
-    if ((int)inl > best) {
-      best = (int)inl;
-      have = true;
-      std::memcpy(Tbest, T, sizeof(T));
-      const double w = (double)best / (double)cnt;
-      double p_no = 1.0 - std::pow(w, 3.0);
-      p_no = std::max(std::numeric_limits<double>::epsilon(), p_no);
-      p_no = std::min(1.0 - std::numeric_limits<double>::epsilon(), p_no);
-      k = std::log(1.0 - 0.99) / std::log(p_no);  // ransac.hpp:102-107
+    for (int b = 0; b < batch && iterations < k && skipped < max_skip; ++b) {
+      if (ht[b].status == 2) {  // no good sample in 1000 draws: computeModel gives up (ransac.hpp:72-76)
+        stop = true;
+        break;
+      }
+      if (ht[b].status == 1) {  // degenerate sample
+        ++skipped;
+        continue;
+      }
+      const unsigned int inl = ht[b].count;
+      if ((int)inl > best) {
+        best = (int)inl;
+        have = true;
+        std::memcpy(Tbest, ht[b].T, sizeof(ht[b].T));
+        const double w = (double)best / (double)cnt;
+        double p_no = 1.0 - std::pow(w, 3.0);
+        p_no = std::max(std::numeric_limits<double>::epsilon(), p_no);
+        p_no = std::min(1.0 - std::numeric_limits<double>::epsilon(), p_no);
+        k = std::log(1.0 - 0.99) / std::log(p_no);  // ransac.hpp:102-107
+      }
+      ++iterations;
+      if (iterations > max_iterations) {
+        stop = true;
+        break;
+      }
     }
-    ++iterations;
-    if (iterations > max_iterations) break;
+    const double left = k - (double)iterations;
+    batch = left > (double)kRansacBatch - 2.0 ? kRansacBatch : std::max(4, (int)std::ceil(left) + 2);
   }
   if (trials) *trials = iterations;
   if (!have) return PCLMI_OK;
-  // selectWithinDistance with the best model
-  unsigned int inl = 0;
+  // selectWithinDistance with the best model (ransac.hpp:124): its population is the count the trial returned (the
+  // same predicate over the same pairs), so the mask is enqueued and nobody waits for it here
   launch_count_within(src, sidx, tgt, tidx, cnt, make_xf(Tbest), thresh, rd.count.p, d_flags, s);
-  PCLMI_HIP(hipMemcpyAsync(&inl, rd.count.p, 4, hipMemcpyDeviceToHost, s));
-  PCLMI_HIP(hipStreamSynchronize(s));
-  *n_inliers = inl;
+  *n_inliers = (unsigned int)best;
   *have_out = true;
   return PCLMI_OK;
 }

@@ -676,9 +676,199 @@ __global__ __launch_bounds__(256) void count_within_kernel(const float4 *__restr
     c += in ? 1 : 0;
     if (flags) flags[i] = in ? 1 : 0;
   }
+  // one atomic per workgroup: with every pair an inlier (a converged ICP iteration) an atomic per wavefront meant
+  // 16 000 adds to one address, 150 of the kernel's 187 us
+  __shared__ int part[4];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-  if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, (unsigned int)c);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int tot = part[0] + part[1] + part[2] + part[3];
+    if (tot) atomicAdd(count, (unsigned int)tot);
+  }
+}
+
+// ---- RANSAC trials in batches ------------------------------------------------------------------------------------
+// The reference draws a sample, fits it, counts its inliers and only then draws the next (ransac.hpp:71-121) - but the
+// draws never depend on the counts (only WHEN to stop does).  So the sampling loop runs here, on the device, where the
+// points are: lane 0 replays the generator and the index shuffle (drawIndexSample, sac_model.h:401-412) and checks
+// isSampleGood (sac_model_registration.hpp:47-60) for up to kRansacBatch trials, the lanes then fit the three-point
+// models in parallel (the same rigid_solve.hpp code as the host's, same bits), and ONE pass over the pairs counts the
+// inliers of every model of the batch.  The host consumes the trials in order and applies the reference's stopping
+// rule; what it discards beyond the stop was drawn from a generator that is re-seeded on every call anyway.
+__global__ void ransac_seed_kernel(RansacRng *rng, unsigned int seed) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  unsigned int x = seed;
+  rng->mt[0] = x;
+  for (int i = 1; i < 624; ++i) {
+    x = 1812433253u * (x ^ (x >> 30)) + (unsigned int)i;
+    rng->mt[i] = x;
+  }
+  rng->idx = 624;
+}
+
+__device__ __forceinline__ unsigned int mt_next(unsigned int *mt, int &idx) {  // one lane; mt in LDS
+  if (idx >= 624) {
+    for (int i = 0; i < 624; ++i) {
+      const unsigned int y = (mt[i] & 0x80000000u) | (mt[(i + 1) % 624] & 0x7fffffffu);
+      mt[i] = mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    idx = 0;
+  }
+  unsigned int y = mt[idx++];
+  y ^= y >> 11;
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= y >> 18;
+  return y;
+}
+
+// loads / stores of the shuffle array that never see a stale line of the vector L1 (a later draw reads what an
+// earlier one stored)
+__device__ __forceinline__ int shuf_ld(const int *p) {
+  return __hip_atomic_load((__attribute__((address_space(1))) const int *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void shuf_st(int *p, int v) {
+  __hip_atomic_store((__attribute__((address_space(1))) int *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(64) void ransac_draw_kernel(RansacRng *__restrict__ rng, int *__restrict__ shuf, int cnt,
+                                                         const float4 *__restrict__ src, const int *__restrict__ sidx,
+                                                         const float4 *__restrict__ tgt, const int *__restrict__ tidx,
+                                                         double sthr, int batch, RansacTrial *__restrict__ trials) {
+  __shared__ unsigned int mt[624];
+  __shared__ float4 six[kRansacBatch][6];
+  __shared__ int status[kRansacBatch];
+  __shared__ double work[kRansacBatch][42];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < 624; i += 64) mt[i] = rng->mt[i];
+  if (lane < kRansacBatch) status[lane] = 2;
+  __syncthreads();
+  if (lane == 0) {
+    int idx = rng->idx;
+    int head[3] = {shuf_ld(shuf + 0), shuf_ld(shuf + 1), shuf_ld(shuf + 2)};  // positions 0..2 live in registers
+    bool dead = false;
+    for (int b = 0; b < batch && !dead; ++b) {
+      bool good = false;
+      for (unsigned int iter = 0; iter < 1000u && !good; ++iter) {  // max_sample_checks_ (sac_model.h:470)
+        // the three swaps of drawIndexSample: shuf[i] <-> shuf[i + rnd() % (cnt - i)], i = 0, 1, 2; the far ends are
+        // loaded together and the swaps replayed on the six entries (0, 1, 2, j0, j1, j2; equal positions share one)
+        int pos[6] = {0, 1, 2, 0, 0, 0}, val[6], canon[6] = {0, 1, 2, 3, 4, 5};
+        for (int i = 0; i < 3; ++i) {
+          const unsigned int r = mt_next(mt, idx) >> 1;
+          pos[3 + i] = i + (int)(r % (unsigned int)(cnt - i));
+        }
+        for (int i = 0; i < 3; ++i) val[i] = head[i];
+        for (int i = 3; i < 6; ++i) val[i] = pos[i] >= 3 ? shuf_ld(shuf + pos[i]) : 0;
+        for (int i = 3; i < 6; ++i)
+          for (int e = 0; e < i; ++e)
+            if (pos[e] == pos[i]) {
+              canon[i] = canon[e];
+              break;
+            }
+        for (int i = 0; i < 3; ++i) {
+          const int a = i, c = canon[3 + i];
+          const int t = val[a];
+          val[a] = val[c];
+          val[c] = t;
+        }
+        for (int i = 3; i < 6; ++i)
+          if (canon[i] == i && pos[i] >= 3) shuf_st(shuf + pos[i], val[i]);
+        for (int i = 0; i < 3; ++i) head[i] = val[i];
+        float4 sp[3], tp[3];
+        for (int i = 0; i < 3; ++i) {
+          sp[i] = src[sidx[head[i]]];
+          tp[i] = tgt[tidx[head[i]]];
+        }
+        auto sq = [](const float4 &u, const float4 &v) {
+          const float dx = u.x - v.x, dy = u.y - v.y, dz = u.z - v.z;
+          return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        };
+        good = (double)sq(sp[1], sp[0]) > sthr && (double)sq(sp[2], sp[0]) > sthr && (double)sq(sp[2], sp[1]) > sthr;
+        if (good) {
+          for (int i = 0; i < 3; ++i) {
+            six[b][2 * i] = sp[i];
+            six[b][2 * i + 1] = tp[i];
+          }
+          status[b] = 0;
+        }
+      }
+      dead = !good;  // ransac.hpp:72-76: computeModel gives up (this and every later trial keep status 2)
+    }
+    for (int i = 0; i < 3; ++i) shuf_st(shuf + i, head[i]);
+    rng->idx = idx;
+  }
+  __syncthreads();
+  for (int i = lane; i < 624; i += 64) rng->mt[i] = mt[i];
+  if (lane < batch) {
+    RansacTrial tr;
+    for (int i = 0; i < 16; ++i) tr.T[i] = (i % 5 == 0) ? 1.f : 0.f;
+    tr.status = status[lane];
+    tr.count = 0u;
+    tr.pad[0] = tr.pad[1] = 0;
+    if (tr.status == 0) {
+      // three-point rigid fit (estimateRigidTransformationSVD, sac_model_registration.hpp:257-302): the sums the
+      // host used to build (api_icp.hip ransac_core), in the same order
+      const float4 *h6 = six[lane];
+      double sm[PCLMI_ICP_NSUMS];
+      for (int i = 0; i < PCLMI_ICP_NSUMS; ++i) sm[i] = 0.0;
+      const double o[3] = {h6[1].x, h6[1].y, h6[1].z};
+      for (int i = 0; i < 3; ++i) {
+        const double sx = h6[2 * i].x - o[0], sy = h6[2 * i].y - o[1], sz = h6[2 * i].z - o[2];
+        const double tx = h6[2 * i + 1].x - o[0], ty = h6[2 * i + 1].y - o[1], tz = h6[2 * i + 1].z - o[2];
+        sm[0] += 1;
+        sm[1] += sx; sm[2] += sy; sm[3] += sz;
+        sm[4] += tx; sm[5] += ty; sm[6] += tz;
+        sm[7] += sx * tx; sm[8] += sx * ty; sm[9] += sx * tz;
+        sm[10] += sy * tx; sm[11] += sy * ty; sm[12] += sy * tz;
+        sm[13] += sz * tx; sm[14] += sz * ty; sm[15] += sz * tz;
+        sm[18] += 1;
+        sm[19] += o[0]; sm[20] += o[1]; sm[21] += o[2];
+      }
+      if (!rs::solve_from_sums(sm, tr.T, work[lane])) tr.status = 1;
+    }
+    trials[lane] = tr;
+  }
+}
+
+__global__ __launch_bounds__(256) void count_within_batch_kernel(const float4 *__restrict__ src,
+                                                                 const int *__restrict__ sidx,
+                                                                 const float4 *__restrict__ tgt,
+                                                                 const int *__restrict__ tidx, int n, double thr2,
+                                                                 int batch, RansacTrial *__restrict__ trials) {
+  __shared__ Xf xf[kRansacBatch];
+  __shared__ int ready[kRansacBatch];
+  __shared__ unsigned int cnt[kRansacBatch];
+  if ((int)threadIdx.x < batch) {
+    const RansacTrial &tr = trials[threadIdx.x];
+    for (int i = 0; i < 12; ++i) xf[threadIdx.x].m[i] = tr.T[i];
+    ready[threadIdx.x] = tr.status == 0;
+    cnt[threadIdx.x] = 0u;
+  }
+  __syncthreads();
+  unsigned int mine = 0u;  // lane b of each wave keeps the wave's running count for model b (and b + 64 ... none: batch <= 64)
+  const int lane = threadIdx.x & 63;
+  for (int i0 = blockIdx.x * blockDim.x; i0 < n; i0 += gridDim.x * blockDim.x) {
+    const int i = i0 + (int)threadIdx.x;
+    const bool live = i < n;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f), q = p;
+    if (live) {
+      p = src[sidx[i]];
+      q = tgt[tidx[i]];
+    }
+    for (int b = 0; b < batch; ++b) {
+      if (!ready[b]) continue;  // block-uniform
+      const float4 m = apply_xf(xf[b], p);
+      const float dx = m.x - q.x, dy = m.y - q.y, dz = m.z - q.z;
+      const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+      const unsigned int c = (unsigned int)__popcll(__ballot(live && (double)d < thr2));
+      if (lane == b) mine += c;
+    }
+  }
+  if (lane < batch && mine) atomicAdd(&cnt[lane], mine);
+  __syncthreads();
+  if ((int)threadIdx.x < batch && cnt[threadIdx.x]) atomicAdd(&trials[threadIdx.x].count, cnt[threadIdx.x]);
 }
 
 // fp32 second moments of the source points of the pair list (computeMeanAndCovarianceMatrix,
@@ -889,9 +1079,27 @@ void launch_count_within(const float4 *src, const int *sidx, const float4 *tgt, 
                          const Xf &T, double thr2, unsigned int *d_count, unsigned char *d_flags, hipStream_t s) {
   (void)hipMemsetAsync(d_count, 0, sizeof(unsigned int), s);
   unsigned b = blocks_for(n, 256);
-  b = b < 1 ? 1 : (b > 4096 ? 4096 : b);
+  b = b < 1 ? 1 : (b > 1024 ? 1024 : b);
   hipLaunchKernelGGL(count_within_kernel, dim3(b), dim3(256), 0, s, src, sidx, tgt, tidx, (int)n, T, thr2, d_count,
                      d_flags);
+}
+
+void launch_ransac_seed(RansacRng *d_rng, unsigned int seed, hipStream_t s) {
+  hipLaunchKernelGGL(ransac_seed_kernel, dim3(1), dim3(64), 0, s, d_rng, seed);
+}
+
+void launch_ransac_draw(RansacRng *d_rng, int *d_shuf, int cnt, const float4 *src, const int *sidx, const float4 *tgt,
+                        const int *tidx, double sample_dist_thresh, int batch, RansacTrial *d_trials, hipStream_t s) {
+  hipLaunchKernelGGL(ransac_draw_kernel, dim3(1), dim3(64), 0, s, d_rng, d_shuf, cnt, src, sidx, tgt, tidx,
+                     sample_dist_thresh, batch, d_trials);
+}
+
+void launch_count_within_batch(const float4 *src, const int *sidx, const float4 *tgt, const int *tidx, size_t n,
+                               double thr2, int batch, RansacTrial *d_trials, hipStream_t s) {
+  unsigned b = blocks_for(n, 256);
+  b = b < 1 ? 1 : (b > 1024 ? 1024 : b);
+  hipLaunchKernelGGL(count_within_batch_kernel, dim3(b), dim3(256), 0, s, src, sidx, tgt, tidx, (int)n, thr2, batch,
+                     d_trials);
 }
 
 void launch_corr_flags(const int *d_nn, const float4 *d_pts, const float4 *d_cloud, const int *d_order, size_t n,

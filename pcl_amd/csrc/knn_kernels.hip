@@ -384,7 +384,9 @@ __global__ __launch_bounds__(64 * WPB)
 
   LaneStack st{0, 0, lane};
   st.push(1);
+#if PCLMI_LEAF_RETEST
   const cbox_ptr box = (cbox_ptr)t.box;
+#endif
   const cgrp_ptr box2 = (cgrp_ptr)t.box;
   const cgrp_ptr leaf = (cgrp_ptr)t.leaf;
   const int M = t.M;

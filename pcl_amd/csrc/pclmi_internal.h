@@ -312,6 +312,26 @@ void launch_moment_reduce(const float4 *src, const int *sidx, size_t n, double *
                           hipStream_t s);
 void launch_count_within(const float4 *src, const int *sidx, const float4 *tgt, const int *tidx, size_t n,
                          const Xf &T, double thr2, unsigned int *d_count, unsigned char *d_flags, hipStream_t s);
+// ---- RANSAC trials in batches (icp_kernels.hip): the sampling loop of RandomSampleConsensus::computeModel runs on the
+// device, up to kRansacBatch trials per launch, and ONE pass over the pairs counts the inliers of all their models
+constexpr int kRansacBatch = 64;
+struct RansacRng {  // std::mt19937 state (boost::mt19937 in the reference, sac_model.h:95)
+  unsigned int mt[624];
+  int idx;
+};
+struct RansacTrial {
+  float T[16];
+  int status;          // 0: model ready, 1: three-point fit failed (a skipped sample), 2: no good sample in 1000 draws
+  unsigned int count;  // inliers of the model (countWithinDistance)
+  int pad[2];
+};
+void launch_ransac_seed(RansacRng *d_rng, unsigned int seed, hipStream_t s);
+// draws the next `batch` trials' samples (drawIndexSample + isSampleGood, up to 1000 draws each) and fits their models
+void launch_ransac_draw(RansacRng *d_rng, int *d_shuf, int cnt, const float4 *src, const int *sidx, const float4 *tgt,
+                        const int *tidx, double sample_dist_thresh, int batch, RansacTrial *d_trials, hipStream_t s);
+// inliers of every ready model of the batch in one pass over the pairs
+void launch_count_within_batch(const float4 *src, const int *sidx, const float4 *tgt, const int *tidx, size_t n,
+                               double thr2, int batch, RansacTrial *d_trials, hipStream_t s);
 void launch_corr_flags(const int *d_nn, const float4 *d_pts, const float4 *d_cloud, const int *d_order, size_t n,
                        double thr2, int *d_tgt_of_orig, unsigned char *d_keep, hipStream_t s);
 void launch_iota(int *v, size_t n, hipStream_t s);
