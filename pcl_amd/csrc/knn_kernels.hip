@@ -771,16 +771,44 @@ __device__ __forceinline__ unsigned int morton_cell(const float *p, float lox, f
 // Hilbert curve are a chain of ~17 small cells of arbitrary shape.  Measured on the 1M x 1M uniform case, k = 16: the
 // union of a wavefront's search balls touches 37 buckets instead of 47.
 // key = tube << 10 | x bin (1024 bins, reversed in odd tubes)
+// tube_p > 0: the tubes are numbered along a 2-D Hilbert curve over a tube_p x tube_p grid (a power of two >= gy, gz)
+// instead of row by row: the ~20 tubes the wavefronts of one XCD work on at a time are then a compact patch of the
+// y-z plane, not a strip across it, and the part of the tree they touch fits the XCD's L2 (FETCH_SIZE 139 -> 116 MB
+// per launch, k = 16 kernel 0.538 -> 0.526 ms).
+__device__ __forceinline__ unsigned int hilbert2d(unsigned int x, unsigned int y, unsigned int n) {
+  unsigned int d = 0u;
+  for (unsigned int s = n >> 1; s > 0u; s >>= 1) {
+    const unsigned int rx = (x & s) ? 1u : 0u, ry = (y & s) ? 1u : 0u;
+    d += s * s * ((3u * rx) ^ ry);
+    if (!ry) {
+      if (rx) {
+        x = n - 1u - x;
+        y = n - 1u - y;
+      }
+      const unsigned int t = x;
+      x = y;
+      y = t;
+    }
+  }
+  return d;
+}
+
+// tube_of: the tube numbers of the tube_p x tube_p grid (the count kernel tabulates hilbert2d once per workgroup, in LDS)
 __device__ __forceinline__ unsigned int tube_key(const float *p, float lox, float loy, float loz, float sx, float sy,
-                                                 float sz, int gy, int gz) {
+                                                 float sz, int gy, int gz, int tube_p,
+                                                 const unsigned int *tube_of) {
   const float fx = (p[0] - lox) * sx, fy = (p[1] - loy) * sy, fz = (p[2] - loz) * sz;
   const unsigned int xb = (unsigned int)fminf(fmaxf(fx, 0.f), 1023.f);  // NaN clamps to 0: order only affects speed
   const unsigned int ty = (unsigned int)fminf(fmaxf(fy, 0.f), (float)(gy - 1));
   const unsigned int tz = (unsigned int)fminf(fmaxf(fz, 0.f), (float)(gz - 1));
-  const unsigned int tube = tz * (unsigned int)gy + ((tz & 1u) ? (unsigned int)gy - 1u - ty : ty);
+  const unsigned int tube = tube_p > 0 ? tube_of[tz * (unsigned int)tube_p + ty]
+                                       : tz * (unsigned int)gy + ((tz & 1u) ? (unsigned int)gy - 1u - ty : ty);
   return (tube << 10) | ((tube & 1u) ? 1023u - xb : xb);
 }
 
+// (Measured and dropped: leaving the queries themselves in sorted order, as 16-byte records carried through the
+// scatter or gathered by bin_sort_kernel, so that the search kernels load them coalesced - the k = 16 kernel gains 19 us
+// (0.526 -> 0.507 ms; its FETCH falls by the 64-byte sector per 12-byte row), the ordering loses 21-25 us.)
 // Query ordering = counting sort by Morton cell.  Only coherence matters (the order inside a
 // cell is irrelevant and results never depend on it), so one histogram pass, one scan and one
 // scatter pass replace a full radix sort.
@@ -824,16 +852,20 @@ constexpr int TILE_TPB = 1024;
 __global__ __launch_bounds__(TILE_TPB) void tile_count_kernel(const float *__restrict__ q, int q_stride_f, int nq, float lox,
                                                               float loy, float loz, float sx, float sy, float sz, int shift,
                                                               int lo_bits, int nb_hi, int tile_size, int ntiles, int gy, int gz,
-                                                              unsigned int *__restrict__ cell, unsigned int *__restrict__ rank,
+                                                              int tube_p, unsigned int *__restrict__ cell,
+                                                              unsigned int *__restrict__ rank,
                                                               unsigned int *__restrict__ tilehist) {
-  extern __shared__ unsigned int lds_hist[];
+  extern __shared__ unsigned int lds_hist[];  // nb_hi counters, then the tube_p x tube_p tube numbers
+  unsigned int *tube_of = lds_hist + nb_hi;
   for (int b = threadIdx.x; b < nb_hi; b += TILE_TPB) lds_hist[b] = 0u;
+  for (int b = threadIdx.x; b < tube_p * tube_p; b += TILE_TPB)
+    tube_of[b] = hilbert2d((unsigned int)(b % tube_p), (unsigned int)(b / tube_p), (unsigned int)tube_p);
   __syncthreads();
   const int tile = blockIdx.x;
   const long long begin = (long long)tile * tile_size;
   const long long end = begin + tile_size < (long long)nq ? begin + tile_size : (long long)nq;
   for (long long i = begin + threadIdx.x; i < end; i += TILE_TPB) {
-    const unsigned int c = gy > 0 ? tube_key(q + (size_t)i * q_stride_f, lox, loy, loz, sx, sy, sz, gy, gz)
+    const unsigned int c = gy > 0 ? tube_key(q + (size_t)i * q_stride_f, lox, loy, loz, sx, sy, sz, gy, gz, tube_p, tube_of)
                                   : morton_cell(q + (size_t)i * q_stride_f, lox, loy, loz, sx, sy, sz, shift);
     cell[i] = c;
     rank[i] = atomicAdd(&lds_hist[c >> lo_bits], 1u);
@@ -923,7 +955,7 @@ int launch_morton_order(const pclmi_tree *t, Workspace *w, const float *d_q, siz
     const char *e = getenv("PCLMI_ORDER");
     return !e ? 0 : (e[0] == 't' ? 1 : (e[0] == 'h' ? 2 : 0));
   }();
-  int gy = 0, gz = 0;
+  int gy = 0, gz = 0, tube_p = 0;
   float tube_sc[3] = {0.f, 0.f, 0.f};
   if (two_level && !w->fixed && order_env != 2 && (order_env == 1 || t->fill >= 0.2f)) {
     const double ex = (double)bb_hi[0] - bb_lo[0], ey = (double)bb_hi[1] - bb_lo[1], ez = (double)bb_hi[2] - bb_lo[2];
@@ -937,16 +969,24 @@ int launch_morton_order(const pclmi_tree *t, Workspace *w, const float *d_q, siz
       gz = (int)(ez / side + 0.5);
       gy = gy < 1 ? 1 : gy;
       gz = gz < 1 ? 1 : gz;
-      while ((long long)gy * gz > 8192) {  // counters of one tile live in LDS
+      while (gy > 64 || gz > 64) {  // counters of one tile live in LDS (64 x 64 tubes at most)
         gy = gy > 1 ? (gy + 1) / 2 : 1;
         gz = gz > 1 ? (gz + 1) / 2 : 1;
+      }
+      static const bool tube_rows = [] {
+        const char *e = getenv("PCLMI_TUBE_WALK");  // development switch: rows = boustrophedon rows of tubes
+        return e && e[0] == 'r';
+      }();
+      if (!tube_rows) {
+        tube_p = 1;
+        while (tube_p < gy || tube_p < gz) tube_p <<= 1;
       }
       tube_sc[0] = (float)(1024.0 / ex);
       tube_sc[1] = (float)(gy / ey);
       tube_sc[2] = (float)(gz / ez);
       lo_bits = 10;
       nb_lo = 1024;
-      nb_hi = gy * gz;
+      nb_hi = tube_p ? tube_p * tube_p : gy * gz;
     }
   }
   int ntiles = (int)((nq + 4095) / 4096);
@@ -963,10 +1003,11 @@ int launch_morton_order(const pclmi_tree *t, Workspace *w, const float *d_q, siz
   TimingScope ts(PCLMI_TIMER_ORDER, s);
   const unsigned grid = (unsigned)((nq + 255) / 256);
   if (two_level) {
-    hipLaunchKernelGGL(tile_count_kernel, dim3(ntiles), dim3(TILE_TPB), (size_t)nb_hi * sizeof(unsigned int), s, d_q,
+    hipLaunchKernelGGL(tile_count_kernel, dim3(ntiles), dim3(TILE_TPB),
+                       ((size_t)nb_hi + (size_t)tube_p * tube_p) * sizeof(unsigned int), s, d_q,
                        (int)q_stride_f, (int)nq, bb_lo[0], bb_lo[1], bb_lo[2], gy ? tube_sc[0] : sc[0],
                        gy ? tube_sc[1] : sc[1], gy ? tube_sc[2] : sc[2], 30 - bits, lo_bits, nb_hi, tile_size, ntiles, gy, gz,
-                       w->keys_in, w->ranks, w->hist);
+                       tube_p, w->keys_in, w->ranks, w->hist);
     size_t tmp = w->cap_tmp;
     PCLMI_HIP(hipcub::DeviceScan::ExclusiveSum(w->sort_tmp, tmp, w->hist, w->hist, nb_hi * ntiles + 1, s));
     hipLaunchKernelGGL(tile_scatter_kernel, dim3(grid), dim3(256), 0, s, w->keys_in, w->ranks, (int)nq, lo_bits, tile_size,
