@@ -62,19 +62,18 @@ __global__ __launch_bounds__(64 * R_WPB) void radius_union_kernel(TreeView t, co
 
   LaneStack st{0, 0, lane};
   st.push(1);
-  const cbox_ptr box = (cbox_ptr)t.box;
   const cgrp_ptr box2 = (cgrp_ptr)t.box;
   const cgrp_ptr leaf = (cgrp_ptr)t.leaf;
   const int M = t.M;
   while (st.sp > 0) {
     const int node = st.pop();
     if (node >= M) {
-      const f8v b = box[node];
+      // no box test here: the bound of a radius search never moves, so expand_inner's test when it pushed the bucket
+      // is the whole truth (a tree of one bucket is scanned untested: 16 exact candidate tests)
       const cgrp_ptr rec = leaf + (size_t)(node - M) * G;
       f16v grp[G];
 #pragma unroll
       for (int g = 0; g < G; ++g) grp[g] = rec[g];
-      if (!__any(box_dist(qx, qy, qz, b[0], b[1], b[2], b[3], b[4], b[5]) <= tau)) continue;
       const f2v q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
 #pragma unroll
       for (int g = 0; g < G; ++g) {
@@ -231,19 +230,16 @@ __global__ __launch_bounds__(64 * RN_WPB) void radius_normals_union_kernel(TreeV
   MomentAcc acc;
   LaneStack st{0, 0, lane};
   st.push(1);
-  const cbox_ptr box = (cbox_ptr)t.box;
   const cgrp_ptr box2 = (cgrp_ptr)t.box;
   const cgrp_ptr leaf = (cgrp_ptr)t.leaf;
   const int M = t.M;
   while (st.sp > 0) {
     const int node = st.pop();
     if (node >= M) {
-      const f8v b = box[node];
-      const cgrp_ptr rec = leaf + (size_t)(node - M) * G;
+      const cgrp_ptr rec = leaf + (size_t)(node - M) * G;  // (no second box test: the bound never moves)
       f16v grp[G];
 #pragma unroll
       for (int g = 0; g < G; ++g) grp[g] = rec[g];
-      if (!__any(box_dist(qx, qy, qz, b[0], b[1], b[2], b[3], b[4], b[5]) <= tau)) continue;
       if (__any(cnt > RN_C - L)) acc.drain(buf, lane, cnt, rows, qx, qy, qz);
       const f2v q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
 #pragma unroll
