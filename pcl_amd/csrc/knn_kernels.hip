@@ -517,17 +517,26 @@ __global__ __launch_bounds__(64) void knn_lane_ix_kernel(TreeView t, const float
   const float qx = lq.x, qy = lq.y, qz = lq.z;
   unsigned int(*buf)[64] = lds;
   const float4 *cloud = reinterpret_cast<const float4 *>(t.slot);
-  const float bound = lq.searchable ? lane_bound<K>(t, qx, qy, qz) : -1.f;
+  // the pre-pass list is kept, as in the union kernel: a[] starts as the K smallest distances of the home buckets, and
+  // in a home bucket the lane appends what is within its bound but inserts nothing
   float a[K];
+  int home = -0x40000000;
+  if (lq.searchable) {
+    lane_bound_list<K>(t, qx, qy, qz, a, home);
+  } else {
 #pragma unroll
-  for (int j = 0; j < K; ++j) a[j] = bound;
+    for (int j = 0; j < K; ++j) a[j] = -1.f;
+  }
+  const float bound = a[K - 1];
   int cnt = 0;
   float dk[K];
   unsigned int ik[K];
   const f2v q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
+  const int M_ = t.M;
   lane_traverse(
       t, qx, qy, qz, lq.searchable, bound, reinterpret_cast<float(*)[64]>(far_lds), lane, 1,
       [&](int leafno, float) {
+        const bool is_home = (unsigned int)(leafno + M_ - home) < (unsigned int)prepass_buckets<K>();
         const float4 *rec = reinterpret_cast<const float4 *>(t.leaf + (size_t)leafno * (4 * L));
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -540,7 +549,7 @@ __global__ __launch_bounds__(64) void knn_lane_ix_kernel(TreeView t, const float
             if (dd[j] <= a[K - 1]) {
               buf[cnt][lane] = (unsigned int)leafno * L + g * 4 + j;  // bucket slot
               ++cnt;
-              list_insert<K>(a, dd[j]);
+              list_insert<K>(a, is_home ? __builtin_inff() : dd[j]);
             }
           }
         }
