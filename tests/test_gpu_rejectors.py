@@ -111,3 +111,34 @@ def test_sample_consensus_rejector_vs_oracle(capi, orc):
     # no model: fewer than 3 pairs keep everything
     g2, T2 = capi.reject_sample_consensus(src, tgt, c[:2], 0.05, 10)
     assert np.array_equal(g2, c[:2]) and np.array_equal(T2, np.eye(4, dtype=np.float32))
+
+
+@pytest.mark.parametrize("outliers,max_iter", [(0.7, 1000), (0.7, 50), (0.9, 1000)])
+def test_sample_consensus_many_trials_vs_oracle(capi, orc, outliers, max_iter):
+    """Few inliers: the stopping rule (ransac.hpp:102-121) asks for ~170 trials at 30 % inliers and for the full 1000 at
+    10 % - several of the library's 64-trial batches, the last one consumed only in part; max_iter = 50 stops inside
+    the first full batch.  Same samples, models and stop as the oracle's one-trial-at-a-time loop."""
+    rng = np.random.default_rng(31)
+    n = 4000
+    src = (rng.random((n, 3), dtype=np.float32) * 10).astype(np.float32)
+    th = np.deg2rad(-12)
+    T0 = np.eye(4, dtype=np.float32)
+    T0[1:3, 1:3] = [[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]]
+    T0[:3, 3] = [0.5, 1.5, -1]
+    tgt = orc.transform(src, T0) + rng.normal(0, 0.004, (n, 3)).astype(np.float32)
+    from pcl_amd.capi import CORR_DTYPE
+    c = np.zeros(n, CORR_DTYPE)
+    c["index_query"] = np.arange(n)
+    c["index_match"] = np.arange(n)
+    bad = rng.permutation(n)[: int(n * outliers)]
+    c["index_match"][bad] = rng.integers(0, n, len(bad))
+    g, T = capi.reject_sample_consensus(src, tgt, c, 0.05, max_iter)
+    pos, To, trials = orc.ransac_registration(src, tgt, c["index_query"], c["index_match"], 0.05, max_iter)
+    assert trials > 40 and pos is not None
+    if len(pos) < 3:
+        # the best of the trials allowed has fewer than three inliers: the rejector keeps every pair
+        # (correspondence_rejection_sample_consensus.hpp:98-105)
+        assert np.array_equal(g, c) and np.array_equal(T, np.eye(4, dtype=np.float32))
+    else:
+        assert np.array_equal(g, c[pos])
+        assert np.abs(T - To).max() < 1e-4
