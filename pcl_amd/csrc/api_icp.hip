@@ -634,8 +634,9 @@ struct RansacDev {
   DevBuf<unsigned int> count;
   DevBuf<float4> six;
   DevBuf<double> partials, sums;
-  DevBuf<RansacRng> rng;
+  DevBuf<RansacRng> rng, rng0;  // rng0: the freshly seeded state (the seed never changes), set up once
   DevBuf<RansacTrial> trials;
+  DevBuf<double> sthr;
   DevBuf<int> shuf;  // shuffled_indices_ (sac_model.h)
   size_t cap_shuf = 0;
   int init(size_t n) {
@@ -645,7 +646,11 @@ struct RansacDev {
     }
     if (count.p) return PCLMI_OK;
     RC(rng.alloc(1));
+    RC(rng0.alloc(1));
+    launch_ransac_seed(rng0.p, 12345u, nullptr);  // boost::mt19937 seed 12345 (sac_model.h:95)
+    PCLMI_HIP(hipStreamSynchronize(nullptr));
     RC(trials.alloc(kRansacBatch));
+    RC(sthr.alloc(1));
     RC(count.alloc(1));
     RC(six.alloc(6));
     RC(partials.alloc((size_t)pair_reduce_blocks(n) * PCLMI_ICP_NSUMS));
@@ -654,39 +659,39 @@ struct RansacDev {
   }
 };
 
+// The passes over ALL pairs (moments, inlier counts, the inlier mask) may run over a superset of the pair list in
+// storage order instead: entry i is (src[i], tgt[tidx[i]]) and exists iff keep[i] (ICP: the source points in the order
+// they are stored in, coalesced, where the pair list in the reference's original-source order is a random gather).
+// d_flags is then indexed like keep.  The samples are always drawn from the pair list (sidx, tidx, cnt).
+struct RansacBulk {
+  const unsigned char *keep;
+  const float4 *tgt;  // rows the bulk passes read the matched points from (may be another copy than the samples')
+  const int *tidx;
+  size_t n;
+};
+
 int ransac_core(RansacDev &rd, const float4 *src, const int *sidx, const float4 *tgt, const int *tidx, int cnt,
                 double inlier_threshold, int max_iterations, unsigned char *d_flags, hipStream_t s, bool *have_out,
-                float Tbest[16], unsigned int *n_inliers, int *trials) {
+                float Tbest[16], unsigned int *n_inliers, int *trials, const RansacBulk *bulk = nullptr) {
   *have_out = false;
   *n_inliers = 0;
   if (trials) *trials = 0;
   set_identity(Tbest);
   if (cnt < 3) return PCLMI_OK;  // getSamples clears the selection, computeModel fails (ransac.hpp:72-76)
-  RC(rd.init((size_t)cnt));
-  // sample_dist_thresh_ (sac_model_registration.h:257-279)
-  double m[PCLMI_ICP_NSUMS];
-  launch_moment_reduce(src, sidx, cnt, rd.partials.p, rd.sums.p, s);
-  PCLMI_HIP(hipMemcpyAsync(m, rd.sums.p, sizeof(m), hipMemcpyDeviceToHost, s));
-  PCLMI_HIP(hipStreamSynchronize(s));
-  const double inv_n = 1.0 / m[9];
-  double a[9];
-  for (int i = 0; i < 9; ++i) a[i] = m[i] * inv_n;
-  const double C00 = a[0] - a[6] * a[6], C01 = a[1] - a[6] * a[7], C02 = a[2] - a[6] * a[8],
-               C11 = a[3] - a[7] * a[7], C12 = a[4] - a[7] * a[8], C22 = a[5] - a[8] * a[8];
-  const double Cm[9] = {C00, C01, C02, C01, C11, C12, C02, C12, C22};
-  double ev[3];
-  sym_eigvals3_f64(Cm, ev);
-  double sthr = 0.0;
-  for (int i = 0; i < 3; ++i) sthr += std::sqrt(ev[i] > 0 ? ev[i] : 0.0);
-  sthr /= 3.0;
-  sthr *= sthr;
+  RC(rd.init(bulk ? std::max(bulk->n, (size_t)cnt) : (size_t)cnt));
+  const int *b_sidx = bulk ? nullptr : sidx, *b_tidx = bulk ? bulk->tidx : tidx;
+  const float4 *b_tgt = bulk ? bulk->tgt : tgt;
+  const unsigned char *b_keep = bulk ? bulk->keep : nullptr;
+  const size_t b_n = bulk ? bulk->n : (size_t)cnt;
+  // sample_dist_thresh_ (sac_model_registration.h:257-279): stays on the device, where the draws use it
+  launch_moment_reduce(src, b_sidx, b_n, rd.partials.p, rd.sums.p, s, b_keep);
+  launch_ransac_sample_threshold(rd.sums.p, rd.sthr.p, s);
 
   // The trials, in batches (icp_kernels.hip "RANSAC trials in batches"): the generator (boost::mt19937, seed 12345,
   // sac_model.h:95; rnd() == gen() >> 1), the index shuffle and isSampleGood run on the device, the three-point models
   // of a batch are fitted in parallel and ONE pass over the pairs counts all their inliers; the host consumes the
   // trials in order under the reference's stopping rule (ransac.hpp:71-121).  One round trip per batch instead of two
   // per trial - with few inliers (a first ICP iteration) the reference's rule asks for hundreds of trials.
-  launch_ransac_seed(rd.rng.p, 12345u, s);
   launch_iota(rd.shuf.p, (size_t)cnt, s);
   const double thresh = inlier_threshold * inlier_threshold;
   int iterations = 0, best = -INT32_MAX;
@@ -695,10 +700,13 @@ int ransac_core(RansacDev &rd, const float4 *src, const int *sidx, const float4 
   const unsigned max_skip = (unsigned)std::min<long long>((long long)max_iterations * 10, 0xffffffffll);
   bool have = false, stop = false;
   RansacTrial ht[kRansacBatch];
-  int batch = 4;  // a converged ICP iteration needs one or two trials
+  int batch = 2;  // a converged ICP iteration needs ONE trial (99.9 % inliers: k < 1 after it)
+  bool first = true;
   while (!stop && iterations < k && skipped < max_skip) {
-    launch_ransac_draw(rd.rng.p, rd.shuf.p, cnt, src, sidx, tgt, tidx, sthr, batch, rd.trials.p, s);
-    launch_count_within_batch(src, sidx, tgt, tidx, (size_t)cnt, thresh, batch, rd.trials.p, s);
+    launch_ransac_draw(first ? rd.rng0.p : rd.rng.p, rd.rng.p, rd.shuf.p, cnt, src, sidx, tgt, tidx, rd.sthr.p, batch,
+                       rd.trials.p, s);
+    first = false;
+    launch_count_within_batch(src, b_sidx, b_tgt, b_tidx, b_n, thresh, batch, rd.trials.p, s, b_keep);
     PCLMI_HIP(hipMemcpyAsync(ht, rd.trials.p, (size_t)batch * sizeof(RansacTrial), hipMemcpyDeviceToHost, s));
     PCLMI_HIP(hipStreamSynchronize(s));
     for (int b = 0; b < batch && iterations < k && skipped < max_skip; ++b) {
@@ -728,13 +736,13 @@ int ransac_core(RansacDev &rd, const float4 *src, const int *sidx, const float4 
       }
     }
     const double left = k - (double)iterations;
-    batch = left > (double)kRansacBatch - 2.0 ? kRansacBatch : std::max(4, (int)std::ceil(left) + 2);
+    batch = left > (double)kRansacBatch - 2.0 ? kRansacBatch : std::max(2, (int)std::ceil(left) + 2);
   }
   if (trials) *trials = iterations;
   if (!have) return PCLMI_OK;
   // selectWithinDistance with the best model (ransac.hpp:124): its population is the count the trial returned (the
   // same predicate over the same pairs), so the mask is enqueued and nobody waits for it here
-  launch_count_within(src, sidx, tgt, tidx, cnt, make_xf(Tbest), thresh, rd.count.p, d_flags, s);
+  launch_count_within(src, b_sidx, b_tgt, b_tidx, b_n, make_xf(Tbest), thresh, rd.count.p, d_flags, s, b_keep);
   *n_inliers = (unsigned int)best;
   *have_out = true;
   return PCLMI_OK;
@@ -743,13 +751,17 @@ int ransac_core(RansacDev &rd, const float4 *src, const int *sidx, const float4 
 struct RansacScratch {
   DevBuf<int> ids, pair_src, pair_slot, pair_tgt, num;
   DevBuf<unsigned char> keep, flags;
+  DevBuf<unsigned char> keep_slot;  // keep in the order the source points are stored in
+  DevBuf<unsigned char> flags_pos;  // the inlier mask by position in the pair list (for the observer)
   DevBuf<int> tgt_of_orig;
   DevBuf<unsigned char> tmp;
   size_t tmp_bytes = 0;
   RansacDev rd;
 };
 
-int ransac_icp(pclmi_icp_ctx *c, RansacScratch &rs, const pclmi_icp_params *p, int64_t *n_inliers,
+// step_pairs: the step's pair count (its sums) - the same predicate over the same pairs as the flags below, so the
+// length of the pair list is known without waiting for the compaction
+int ransac_icp(pclmi_icp_ctx *c, RansacScratch &rs, const pclmi_icp_params *p, int64_t step_pairs, int64_t *n_inliers,
                double *sums_out /* c->nsums() */) {
   *n_inliers = -1;
   const size_t n = c->n;
@@ -762,6 +774,8 @@ int ransac_icp(pclmi_icp_ctx *c, RansacScratch &rs, const pclmi_icp_params *p, i
     RC(rs.pair_tgt.alloc(n));
     RC(rs.num.alloc(1));
     RC(rs.keep.alloc(n));
+    RC(rs.keep_slot.alloc(n));
+    RC(rs.flags_pos.alloc(n));
     RC(rs.flags.alloc(n));
     RC(rs.tgt_of_orig.alloc(n));
     launch_iota(rs.ids.p, n, s);
@@ -771,27 +785,34 @@ int ransac_icp(pclmi_icp_ctx *c, RansacScratch &rs, const pclmi_icp_params *p, i
     RC(rs.tmp.alloc(rs.tmp_bytes));
   }
   // kept pairs in ORIGINAL source order (the order the reference's index lists have)
-  launch_corr_flags(c->nn.p, c->pts.p, cloud, c->order.p, n, c->last_thr2, rs.tgt_of_orig.p, rs.keep.p, s);
+  const float4 *rows = (const float4 *)c->tree->d_slot;  // bucket-slot copy of the target (same coordinates)
+  launch_corr_flags(c->nn.p, c->pts.p, cloud, c->order.p, n, c->last_thr2, rs.tgt_of_orig.p, rs.keep.p, s,
+                    rs.keep_slot.p, rows, c->nn_slot.p);
   RC(select_flagged(rs.ids.p, rs.keep.p, n, rs.pair_src.p, rs.num.p, rs.tmp.p, rs.tmp_bytes, nullptr, s));
-  int cnt = 0;
-  PCLMI_HIP(hipMemcpyAsync(&cnt, rs.num.p, 4, hipMemcpyDeviceToHost, s));
-  PCLMI_HIP(hipStreamSynchronize(s));
+  const int cnt = (int)step_pairs;
+  int cnt_check = -1;  // arrives with ransac_core's first round trip
+  PCLMI_HIP(hipMemcpyAsync(&cnt_check, rs.num.p, 4, hipMemcpyDeviceToHost, s));
   if (cnt < 3) return PCLMI_OK;
   launch_gather_int(c->inv.p, rs.pair_src.p, cnt, rs.pair_slot.p, s);
   launch_gather_int(rs.tgt_of_orig.p, rs.pair_src.p, cnt, rs.pair_tgt.p, s);
   bool have = false;
   float Tbest[16];
   unsigned int inl = 0;
+  // the passes over all pairs walk the source points as they are stored (c->pts with their neighbours c->nn and the
+  // mask keep_slot): coalesced, where the pair list in original-source order is a random gather; rs.flags comes back
+  // indexed the same way
+  const RansacBulk bulk{rs.keep_slot.p, rows, c->nn_slot.p, n};
   RC(ransac_core(rs.rd, c->pts.p, rs.pair_slot.p, cloud, rs.pair_tgt.p, cnt, p->ransac_outlier_threshold,
-                 p->ransac_iterations, rs.flags.p, s, &have, Tbest, &inl, nullptr));
+                 p->ransac_iterations, rs.flags.p, s, &have, Tbest, &inl, nullptr, &bulk));
+  PCLMI_CHECK(cnt_check == cnt, PCLMI_ERR_HIP, "internal: the step counted %d pairs, the pair list holds %d", cnt,
+              cnt_check);
   if (!have) return PCLMI_OK;
   // the sums of the inlier pairs, for the refit (icp.hpp:171 on the *_good index lists)
   if (c->plane)
-    launch_pair_reduce_plane(c->pts.p, rs.pair_slot.p, cloud, rs.pair_tgt.p, c->tn_rows.p,
-                             c->has_skip ? c->src_skip.p : nullptr, rs.flags.p, cnt, c->partials.p, c->sums.p, s);
+    launch_pair_reduce_plane(c->pts.p, nullptr, rows, c->nn_slot.p, c->tn_slot.p, c->has_skip ? c->src_skip.p : nullptr,
+                             rs.flags.p, n, c->partials.p, c->sums.p, s);
   else
-    launch_pair_reduce(c->pts.p, rs.pair_slot.p, cloud, rs.pair_tgt.p, rs.flags.p, cnt, c->origin, c->partials.p,
-                       c->sums.p, s);
+    launch_pair_reduce(c->pts.p, nullptr, rows, c->nn_slot.p, rs.flags.p, n, c->origin, c->partials.p, c->sums.p, s);
   PCLMI_HIP(hipMemcpyAsync(sums_out, c->sums.p, (size_t)c->nsums() * sizeof(double), hipMemcpyDeviceToHost, s));
   PCLMI_HIP(hipStreamSynchronize(s));
   *n_inliers = inl;
@@ -959,13 +980,14 @@ int align_core(const pclmi_icp_params *p, const pclmi_tree *target, const float 
     double rsums[PCLMI_ICP_NSUMS_PLANE];
     {  // icp.hpp:113-150
       int64_t ninl = -1;
-      if ((rc = ransac_icp(c, rs, p, &ninl, rsums))) break;
+      if ((rc = ransac_icp(c, rs, p, cnt, &ninl, rsums))) break;
       if (ninl >= 0) {
         used = ninl;
         solve_sums = rsums;  // pair sums of the inliers only
       }
       if (obs.fn) {  // the pairs the estimator is about to get (icp.hpp:130-149)
-        rc = ninl >= 0 ? obs.pairs_from_inliers(c, rs.pair_src.p, rs.pair_tgt.p, rs.flags.p, (size_t)cnt)
+        if (ninl >= 0) launch_gather_u8(rs.flags.p, rs.pair_slot.p, (size_t)cnt, rs.flags_pos.p, c->stream);
+        rc = ninl >= 0 ? obs.pairs_from_inliers(c, rs.pair_src.p, rs.pair_tgt.p, rs.flags_pos.p, (size_t)cnt)
                        : obs.pairs_from_flags(c, rs.keep.p, rs.tgt_of_orig.p);
         if (rc) break;
       }

@@ -665,14 +665,18 @@ __global__ __launch_bounds__(256) void count_within_kernel(const float4 *__restr
                                                            const float4 *__restrict__ tgt,
                                                            const int *__restrict__ tidx, int n, Xf T, double thr2,
                                                            unsigned int *__restrict__ count,
-                                                           unsigned char *__restrict__ flags) {
+                                                           unsigned char *__restrict__ flags,
+                                                           const unsigned char *__restrict__ keep) {
   int c = 0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const float4 p = apply_xf(T, src[sidx[i]]);
-    const float4 q = tgt[tidx[i]];
-    const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
-    const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-    const bool in = (double)d < thr2;
+    bool in = false;
+    if (!keep || keep[i]) {  // sidx == nullptr: pair i is (src[i], tgt[tidx[i]]); keep: pairs that exist
+      const float4 p = apply_xf(T, src[sidx ? sidx[i] : i]);
+      const float4 q = tgt[tidx[i]];
+      const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
+      const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+      in = (double)d < thr2;
+    }
     c += in ? 1 : 0;
     if (flags) flags[i] = in ? 1 : 0;
   }
@@ -697,6 +701,47 @@ __global__ __launch_bounds__(256) void count_within_kernel(const float4 *__restr
 // models in parallel (the same rigid_solve.hpp code as the host's, same bits), and ONE pass over the pairs counts the
 // inliers of every model of the batch.  The host consumes the trials in order and applies the reference's stopping
 // rule; what it discards beyond the stop was drawn from a generator that is re-seeded on every call anyway.
+// sample_dist_thresh_ = (mean of the square roots of the eigenvalues of the source points' covariance)^2
+// (computeSampleDistanceThreshold, sac_model_registration.h:257-279; cyclic Jacobi stands in for pcl::eigen33).
+// m: the sums of moment_reduce_kernel (second moments 0..5, first moments 6..8, count 9).
+__global__ void ransac_sample_threshold_kernel(const double *__restrict__ m, double *__restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double inv_n = 1.0 / m[9];
+  double a[9];
+  for (int i = 0; i < 9; ++i) a[i] = m[i] * inv_n;
+  const double C00 = a[0] - a[6] * a[6], C01 = a[1] - a[6] * a[7], C02 = a[2] - a[6] * a[8],
+               C11 = a[3] - a[7] * a[7], C12 = a[4] - a[7] * a[8], C22 = a[5] - a[8] * a[8];
+  double c[9] = {C00, C01, C02, C01, C11, C12, C02, C12, C22};
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    // converged: the off-diagonal part is below the last bit of the diagonal, further rotations change nothing
+    const double off = fabs(c[1]) + fabs(c[2]) + fabs(c[5]);
+    if (off <= 1e-22 * (fabs(c[0]) + fabs(c[4]) + fabs(c[8])) || off < 1e-300) break;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        const double apq = c[p * 3 + q];
+        if (fabs(apq) < 1e-300) continue;
+        const double theta = (c[q * 3 + q] - c[p * 3 + p]) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+        for (int k = 0; k < 3; ++k) {
+          const double akp = c[k * 3 + p], akq = c[k * 3 + q];
+          c[k * 3 + p] = cs * akp - sn * akq;
+          c[k * 3 + q] = sn * akp + cs * akq;
+        }
+        for (int k = 0; k < 3; ++k) {
+          const double apk = c[p * 3 + k], aqk = c[q * 3 + k];
+          c[p * 3 + k] = cs * apk - sn * aqk;
+          c[q * 3 + k] = sn * apk + cs * aqk;
+        }
+      }
+  }
+  const double ev[3] = {c[0], c[4], c[8]};
+  double sthr = 0.0;
+  for (int i = 0; i < 3; ++i) sthr += sqrt(ev[i] > 0 ? ev[i] : 0.0);
+  sthr /= 3.0;
+  out[0] = sthr * sthr;
+}
+
 __global__ void ransac_seed_kernel(RansacRng *rng, unsigned int seed) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   unsigned int x = seed;
@@ -733,20 +778,25 @@ __device__ __forceinline__ void shuf_st(int *p, int v) {
   __hip_atomic_store((__attribute__((address_space(1))) int *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ __launch_bounds__(64) void ransac_draw_kernel(RansacRng *__restrict__ rng, int *__restrict__ shuf, int cnt,
+// rng_in: the generator state to continue from - the freshly seeded one (kept per RansacDev: the seed never changes) for
+// the first batch of a call, rng itself afterwards
+__global__ __launch_bounds__(64) void ransac_draw_kernel(const RansacRng *__restrict__ rng_in, RansacRng *__restrict__ rng,
+                                                         int *__restrict__ shuf, int cnt,
                                                          const float4 *__restrict__ src, const int *__restrict__ sidx,
                                                          const float4 *__restrict__ tgt, const int *__restrict__ tidx,
-                                                         double sthr, int batch, RansacTrial *__restrict__ trials) {
+                                                         const double *__restrict__ sthr_p, int batch,
+                                                         RansacTrial *__restrict__ trials) {
   __shared__ unsigned int mt[624];
   __shared__ float4 six[kRansacBatch][6];
   __shared__ int status[kRansacBatch];
   __shared__ double work[kRansacBatch][42];
   const int lane = threadIdx.x;
-  for (int i = lane; i < 624; i += 64) mt[i] = rng->mt[i];
+  for (int i = lane; i < 624; i += 64) mt[i] = rng_in->mt[i];
   if (lane < kRansacBatch) status[lane] = 2;
   __syncthreads();
   if (lane == 0) {
-    int idx = rng->idx;
+    const double sthr = sthr_p[0];
+    int idx = rng_in->idx;
     int head[3] = {shuf_ld(shuf + 0), shuf_ld(shuf + 1), shuf_ld(shuf + 2)};  // positions 0..2 live in registers
     bool dead = false;
     for (int b = 0; b < batch && !dead; ++b) {
@@ -836,7 +886,8 @@ __global__ __launch_bounds__(256) void count_within_batch_kernel(const float4 *_
                                                                  const int *__restrict__ sidx,
                                                                  const float4 *__restrict__ tgt,
                                                                  const int *__restrict__ tidx, int n, double thr2,
-                                                                 int batch, RansacTrial *__restrict__ trials) {
+                                                                 int batch, RansacTrial *__restrict__ trials,
+                                                                 const unsigned char *__restrict__ keep) {
   __shared__ Xf xf[kRansacBatch];
   __shared__ int ready[kRansacBatch];
   __shared__ unsigned int cnt[kRansacBatch];
@@ -851,10 +902,10 @@ __global__ __launch_bounds__(256) void count_within_batch_kernel(const float4 *_
   const int lane = threadIdx.x & 63;
   for (int i0 = blockIdx.x * blockDim.x; i0 < n; i0 += gridDim.x * blockDim.x) {
     const int i = i0 + (int)threadIdx.x;
-    const bool live = i < n;
+    const bool live = i < n && (!keep || keep[i]);
     float4 p = make_float4(0.f, 0.f, 0.f, 0.f), q = p;
     if (live) {
-      p = src[sidx[i]];
+      p = src[sidx ? sidx[i] : i];
       q = tgt[tidx[i]];
     }
     for (int b = 0; b < batch; ++b) {
@@ -873,8 +924,10 @@ __global__ __launch_bounds__(256) void count_within_batch_kernel(const float4 *_
 
 // fp32 second moments of the source points of the pair list (computeMeanAndCovarianceMatrix,
 // common/include/pcl/common/impl/centroid.hpp:553-617), accumulated in fp64
+// sidx == nullptr: entry i is src[i]; keep (nullable): entries whose byte is 0 do not exist
 __global__ __launch_bounds__(64 * PR_WPB) void moment_reduce_kernel(const float4 *__restrict__ src,
                                                                      const int *__restrict__ sidx, int n,
+                                                                     const unsigned char *__restrict__ keep,
                                                                      double *__restrict__ partials) {
   __shared__ double lds[PR_WPB][NS];
   const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
@@ -882,7 +935,8 @@ __global__ __launch_bounds__(64 * PR_WPB) void moment_reduce_kernel(const float4
 #pragma unroll
   for (int j = 0; j < NS; ++j) acc[j] = 0.0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const float4 p = src[sidx[i]];
+    if (keep && !keep[i]) continue;
+    const float4 p = src[sidx ? sidx[i] : i];
     const double x = p.x, y = p.y, z = p.z;
     acc[0] += x * x; acc[1] += x * y; acc[2] += x * z;
     acc[3] += y * y; acc[4] += y * z; acc[5] += z * z;
@@ -893,22 +947,33 @@ __global__ __launch_bounds__(64 * PR_WPB) void moment_reduce_kernel(const float4
 }
 
 // correspondences of the last step in ORIGINAL source order: keep[orig] = d2 < thr2
+// rows / row_of (nullable): the matched point's coordinates come from rows[row_of[i]] instead of cloud[nn_idx[i]] -
+// the bucket-slot copy, where the neighbours of neighbouring source points sit next to each other
 __global__ void corr_flags_kernel(const int *__restrict__ nn_idx, const float4 *__restrict__ pts,
-                                  const float4 *__restrict__ cloud, const int *__restrict__ order, int n,
-                                  double thr2, int *__restrict__ tgt_of_orig, unsigned char *__restrict__ keep) {
+                                  const float4 *__restrict__ cloud, const float4 *__restrict__ rows,
+                                  const int *__restrict__ row_of, const int *__restrict__ order, int n,
+                                  double thr2, int *__restrict__ tgt_of_orig, unsigned char *__restrict__ keep,
+                                  unsigned char *__restrict__ keep_slot) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int o = order[i];
   const int j = nn_idx[i];
   bool k = false;
   if (j >= 0) {
-    const float4 p = pts[i], q = cloud[j];
+    const float4 p = pts[i], q = rows ? rows[row_of[i]] : cloud[j];
     const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
     const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
     k = (double)d < thr2;
   }
   tgt_of_orig[o] = j;
   keep[o] = k ? 1 : 0;
+  if (keep_slot) keep_slot[i] = k ? 1 : 0;  // the same mask in the order the points are stored in
+}
+
+__global__ void gather_u8_kernel(const unsigned char *__restrict__ in, const int *__restrict__ idx, int n,
+                                 unsigned char *__restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[idx[i]];
 }
 
 __global__ void iota_kernel(int *__restrict__ v, int n) {
@@ -1068,45 +1133,56 @@ void launch_corr_reduce(const float *src, size_t src_stride_f, const float *tgt,
 }
 
 void launch_moment_reduce(const float4 *src, const int *sidx, size_t n, double *d_partials, double *d_sums,
-                          hipStream_t s) {
+                          hipStream_t s, const unsigned char *keep) {
   const unsigned blocks = pair_reduce_blocks(n);
-  hipLaunchKernelGGL(moment_reduce_kernel, dim3(blocks), dim3(64 * PR_WPB), 0, s, src, sidx, (int)n, d_partials);
+  hipLaunchKernelGGL(moment_reduce_kernel, dim3(blocks), dim3(64 * PR_WPB), 0, s, src, sidx, (int)n, keep, d_partials);
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(NS), dim3(256), 0, s, d_partials, (int)blocks, (size_t)NS, (size_t)1,
                      d_sums);
 }
 
 void launch_count_within(const float4 *src, const int *sidx, const float4 *tgt, const int *tidx, size_t n,
-                         const Xf &T, double thr2, unsigned int *d_count, unsigned char *d_flags, hipStream_t s) {
+                         const Xf &T, double thr2, unsigned int *d_count, unsigned char *d_flags, hipStream_t s,
+                         const unsigned char *keep) {
   (void)hipMemsetAsync(d_count, 0, sizeof(unsigned int), s);
   unsigned b = blocks_for(n, 256);
   b = b < 1 ? 1 : (b > 1024 ? 1024 : b);
   hipLaunchKernelGGL(count_within_kernel, dim3(b), dim3(256), 0, s, src, sidx, tgt, tidx, (int)n, T, thr2, d_count,
-                     d_flags);
+                     d_flags, keep);
 }
 
 void launch_ransac_seed(RansacRng *d_rng, unsigned int seed, hipStream_t s) {
   hipLaunchKernelGGL(ransac_seed_kernel, dim3(1), dim3(64), 0, s, d_rng, seed);
 }
 
-void launch_ransac_draw(RansacRng *d_rng, int *d_shuf, int cnt, const float4 *src, const int *sidx, const float4 *tgt,
-                        const int *tidx, double sample_dist_thresh, int batch, RansacTrial *d_trials, hipStream_t s) {
-  hipLaunchKernelGGL(ransac_draw_kernel, dim3(1), dim3(64), 0, s, d_rng, d_shuf, cnt, src, sidx, tgt, tidx,
-                     sample_dist_thresh, batch, d_trials);
+void launch_ransac_draw(const RansacRng *d_rng_in, RansacRng *d_rng, int *d_shuf, int cnt, const float4 *src,
+                        const int *sidx, const float4 *tgt, const int *tidx, const double *d_sample_dist_thresh, int batch,
+                        RansacTrial *d_trials, hipStream_t s) {
+  hipLaunchKernelGGL(ransac_draw_kernel, dim3(1), dim3(64), 0, s, d_rng_in, d_rng, d_shuf, cnt, src, sidx, tgt, tidx,
+                     d_sample_dist_thresh, batch, d_trials);
+}
+
+void launch_ransac_sample_threshold(const double *d_moment_sums, double *d_out, hipStream_t s) {
+  hipLaunchKernelGGL(ransac_sample_threshold_kernel, dim3(1), dim3(64), 0, s, d_moment_sums, d_out);
 }
 
 void launch_count_within_batch(const float4 *src, const int *sidx, const float4 *tgt, const int *tidx, size_t n,
-                               double thr2, int batch, RansacTrial *d_trials, hipStream_t s) {
+                               double thr2, int batch, RansacTrial *d_trials, hipStream_t s, const unsigned char *keep) {
   unsigned b = blocks_for(n, 256);
   b = b < 1 ? 1 : (b > 1024 ? 1024 : b);
   hipLaunchKernelGGL(count_within_batch_kernel, dim3(b), dim3(256), 0, s, src, sidx, tgt, tidx, (int)n, thr2, batch,
-                     d_trials);
+                     d_trials, keep);
 }
 
 void launch_corr_flags(const int *d_nn, const float4 *d_pts, const float4 *d_cloud, const int *d_order, size_t n,
-                       double thr2, int *d_tgt_of_orig, unsigned char *d_keep, hipStream_t s) {
+                       double thr2, int *d_tgt_of_orig, unsigned char *d_keep, hipStream_t s,
+                       unsigned char *d_keep_slot, const float4 *d_rows, const int *d_row_of) {
   if (n)
-    hipLaunchKernelGGL(corr_flags_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, d_nn, d_pts, d_cloud, d_order,
-                       (int)n, thr2, d_tgt_of_orig, d_keep);
+    hipLaunchKernelGGL(corr_flags_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, d_nn, d_pts, d_cloud, d_rows,
+                       d_row_of, d_order, (int)n, thr2, d_tgt_of_orig, d_keep, d_keep_slot);
+}
+
+void launch_gather_u8(const unsigned char *in, const int *idx, size_t n, unsigned char *out, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(gather_u8_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, in, idx, (int)n, out);
 }
 
 void launch_iota(int *v, size_t n, hipStream_t s) {

@@ -309,9 +309,11 @@ void launch_pair_reduce(const float4 *src, const int *sidx, const float4 *tgt, c
 void launch_corr_reduce(const float *src, size_t src_stride_f, const float *tgt, size_t tgt_stride_f,
                         const pclmi_correspondence *corr, size_t n, double *d_partials, double *d_sums, hipStream_t s);
 void launch_moment_reduce(const float4 *src, const int *sidx, size_t n, double *d_partials, double *d_sums,
-                          hipStream_t s);
+                          hipStream_t s, const unsigned char *keep = nullptr);
 void launch_count_within(const float4 *src, const int *sidx, const float4 *tgt, const int *tidx, size_t n,
-                         const Xf &T, double thr2, unsigned int *d_count, unsigned char *d_flags, hipStream_t s);
+                         const Xf &T, double thr2, unsigned int *d_count, unsigned char *d_flags, hipStream_t s,
+                         const unsigned char *keep = nullptr);
+void launch_gather_u8(const unsigned char *in, const int *idx, size_t n, unsigned char *out, hipStream_t s);
 // ---- RANSAC trials in batches (icp_kernels.hip): the sampling loop of RandomSampleConsensus::computeModel runs on the
 // device, up to kRansacBatch trials per launch, and ONE pass over the pairs counts the inliers of all their models
 constexpr int kRansacBatch = 64;
@@ -327,13 +329,20 @@ struct RansacTrial {
 };
 void launch_ransac_seed(RansacRng *d_rng, unsigned int seed, hipStream_t s);
 // draws the next `batch` trials' samples (drawIndexSample + isSampleGood, up to 1000 draws each) and fits their models
-void launch_ransac_draw(RansacRng *d_rng, int *d_shuf, int cnt, const float4 *src, const int *sidx, const float4 *tgt,
-                        const int *tidx, double sample_dist_thresh, int batch, RansacTrial *d_trials, hipStream_t s);
+// d_sample_dist_thresh: sample_dist_thresh_ of the model, left on the device by launch_ransac_sample_threshold
+void launch_ransac_draw(const RansacRng *d_rng_in, RansacRng *d_rng, int *d_shuf, int cnt, const float4 *src,
+                        const int *sidx, const float4 *tgt, const int *tidx, const double *d_sample_dist_thresh, int batch,
+                        RansacTrial *d_trials, hipStream_t s);
+// computeSampleDistanceThreshold (sac_model_registration.h:257-279) from the moment sums of launch_moment_reduce
+void launch_ransac_sample_threshold(const double *d_moment_sums, double *d_out, hipStream_t s);
 // inliers of every ready model of the batch in one pass over the pairs
 void launch_count_within_batch(const float4 *src, const int *sidx, const float4 *tgt, const int *tidx, size_t n,
-                               double thr2, int batch, RansacTrial *d_trials, hipStream_t s);
+                               double thr2, int batch, RansacTrial *d_trials, hipStream_t s,
+                               const unsigned char *keep = nullptr);
 void launch_corr_flags(const int *d_nn, const float4 *d_pts, const float4 *d_cloud, const int *d_order, size_t n,
-                       double thr2, int *d_tgt_of_orig, unsigned char *d_keep, hipStream_t s);
+                       double thr2, int *d_tgt_of_orig, unsigned char *d_keep, hipStream_t s,
+                       unsigned char *d_keep_slot = nullptr, const float4 *d_rows = nullptr,
+                       const int *d_row_of = nullptr);
 void launch_iota(int *v, size_t n, hipStream_t s);
 void launch_gather_int(const int *in, const int *idx, size_t n, int *out, hipStream_t s);
 void launch_gather_points(const float4 *a, const int *ia, const float4 *b, const int *ib, const int pos[3],
@@ -350,7 +359,6 @@ void launch_normals(const pclmi_tree *t, const float *d_q, size_t q_stride_f, si
 void svd3_f64(const double A[9], double U[9], double S[3], double V[9]);
 int solve_rigid_from_sums(const double sums[PCLMI_ICP_NSUMS], float T[16]);
 void mat4_mul_f32(const float A[16], const float B[16], float C[16]);
-void sym_eigvals3_f64(const double M[9], double ev[3]);
 int solve_point_to_plane(const double sums[27], float T[16]);
 
 }  // namespace pclmi

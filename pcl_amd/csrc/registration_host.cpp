@@ -44,38 +44,6 @@ int solve_point_to_plane(const double sums[27], float T[16]) {
   return PCLMI_OK;
 }
 
-// eigenvalues of a symmetric 3x3 by cyclic Jacobi (stands in for pcl::eigen33 in
-// SampleConsensusModelRegistration::computeSampleDistanceThreshold, sac_model_registration.h:257-279)
-void sym_eigvals3_f64(const double Min[9], double ev[3]) {
-  double a[9];
-  std::memcpy(a, Min, sizeof(a));
-  for (int sweep = 0; sweep < 60; ++sweep) {
-    const double off = std::fabs(a[1]) + std::fabs(a[2]) + std::fabs(a[5]);
-    if (off < 1e-300) break;
-    for (int p = 0; p < 2; ++p)
-      for (int q = p + 1; q < 3; ++q) {
-        const double apq = a[p * 3 + q];
-        if (std::fabs(apq) < 1e-300) continue;
-        const double theta = (a[q * 3 + q] - a[p * 3 + p]) / (2.0 * apq);
-        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-        const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
-        for (int k = 0; k < 3; ++k) {
-          const double akp = a[k * 3 + p], akq = a[k * 3 + q];
-          a[k * 3 + p] = c * akp - s * akq;
-          a[k * 3 + q] = s * akp + c * akq;
-        }
-        for (int k = 0; k < 3; ++k) {
-          const double apk = a[p * 3 + k], aqk = a[q * 3 + k];
-          a[p * 3 + k] = c * apk - s * aqk;
-          a[q * 3 + k] = s * apk + c * aqk;
-        }
-      }
-  }
-  ev[0] = a[0];
-  ev[1] = a[4];
-  ev[2] = a[8];
-}
-
 }  // namespace pclmi
 
 extern "C" int pclmi_icp_solve(const double sums[PCLMI_ICP_NSUMS], float T[16]) {
