@@ -177,7 +177,7 @@ __device__ __forceinline__ void knn_finish(unsigned int (*buf)[64], const float4
                                            float *__restrict__ out_d2) {
   const float qx = lq.x, qy = lq.y, qz = lq.z;
   unsigned long long key[K];
-  if constexpr (PCLMI_FINISH_ONE_GATHER && K >= 16) {
+  if constexpr (PCLMI_FINISH_ONE_GATHER && K >= 16 && C / 2 >= K) {
   // ---- final: ONE gather per buffered candidate (K >= 16; below that the two-pass form is faster: 0.29 vs 0.26 ms
   // per 1M queries at K = 2, 0.41 vs 0.39 at K = 8, but 0.609 vs 0.622 at K = 16, 1.34 vs 1.36 at K = 32).  All bucket slots of the lane's buffer are read into registers
   // first, so the buffer's own LDS rows can take the survivors' (d2, index) keys (two rows per key) while the rows are
@@ -337,9 +337,12 @@ __device__ __forceinline__ void normals_finish(unsigned int (*buf)[64], const fl
 #ifndef PCLMI_WAVES16
 #define PCLMI_WAVES16 4
 #endif
+#ifndef PCLMI_WAVES32
+#define PCLMI_WAVES32 2
+#endif
 template <int K, int C, int WPB, bool NRM = false>
 __global__ __launch_bounds__(64 * WPB)
-    __attribute__((amdgpu_waves_per_eu(K == 16 ? PCLMI_WAVES16 : K <= 4 ? 7 : K == 8 ? 6 : K == 32 ? 2 : 1))) void knn_union_ix_kernel(TreeView t, const float *__restrict__ q,
+    __attribute__((amdgpu_waves_per_eu(K == 16 ? PCLMI_WAVES16 : K <= 4 ? 7 : K == 8 ? 6 : K == 32 ? PCLMI_WAVES32 : 1))) void knn_union_ix_kernel(TreeView t, const float *__restrict__ q,
                                                                  int q_stride_f, const int *__restrict__ order,
                                                                  int nq, int k_out, int *__restrict__ out_idx,
                                                                  float *__restrict__ out_d2, float vpx, float vpy,

@@ -1,3 +1,4 @@
+# development: rocprofv3 kernel stats of the ordering kernels and the k=16 kernel for library variants
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for v in default bt512 bt1024; do
   lib=pcl_amd/lib/libpclmi_$v.so; [ "$v" = default ] && lib=pcl_amd/lib/libpclmi.so

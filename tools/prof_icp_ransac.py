@@ -1,3 +1,5 @@
+"""Two default-parameter (RANSAC on) 30-iteration aligns of configs[3]'s clouds, for rocprofv3 --kernel-trace
+(development helper: the timeline of one iteration was read off its kernel trace)."""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import bench
