@@ -757,6 +757,10 @@ struct RansacScratch {
   DevBuf<unsigned char> tmp;
   size_t tmp_bytes = 0;
   RansacDev rd;
+  bool all_kept = false;  // the pair list of the current iteration is the identity (every source point has a pair)
+  const int *src_of_pair() const { return all_kept ? ids.p : pair_src.p; }
+  const int *tgt_of_pair() const { return all_kept ? tgt_of_orig.p : pair_tgt.p; }
+  const int *slot_of_pair(const pclmi_icp_ctx *c) const { return all_kept ? c->inv.p : pair_slot.p; }
 };
 
 // step_pairs: the step's pair count (its sums) - the same predicate over the same pairs as the flags below, so the
@@ -788,13 +792,23 @@ int ransac_icp(pclmi_icp_ctx *c, RansacScratch &rs, const pclmi_icp_params *p, i
   const float4 *rows = (const float4 *)c->tree->d_slot;  // bucket-slot copy of the target (same coordinates)
   launch_corr_flags(c->nn.p, c->pts.p, cloud, c->order.p, n, c->last_thr2, rs.tgt_of_orig.p, rs.keep.p, s,
                     rs.keep_slot.p, rows, c->nn_slot.p);
-  RC(select_flagged(rs.ids.p, rs.keep.p, n, rs.pair_src.p, rs.num.p, rs.tmp.p, rs.tmp_bytes, nullptr, s));
   const int cnt = (int)step_pairs;
   int cnt_check = -1;  // arrives with ransac_core's first round trip
-  PCLMI_HIP(hipMemcpyAsync(&cnt_check, rs.num.p, 4, hipMemcpyDeviceToHost, s));
+  // the pair list the samples are drawn from: (source row, its slot, target row) of the kept pairs in original-source
+  // order.  When EVERY source point has a pair (a generous distance threshold: the usual state of a converging align)
+  // the list is the identity - no compaction, no gathers
+  rs.all_kept = (size_t)cnt == n;
+  if (rs.all_kept) {
+    cnt_check = cnt;
+  } else {
+    RC(select_flagged(rs.ids.p, rs.keep.p, n, rs.pair_src.p, rs.num.p, rs.tmp.p, rs.tmp_bytes, nullptr, s));
+    PCLMI_HIP(hipMemcpyAsync(&cnt_check, rs.num.p, 4, hipMemcpyDeviceToHost, s));
+  }
   if (cnt < 3) return PCLMI_OK;
-  launch_gather_int(c->inv.p, rs.pair_src.p, cnt, rs.pair_slot.p, s);
-  launch_gather_int(rs.tgt_of_orig.p, rs.pair_src.p, cnt, rs.pair_tgt.p, s);
+  if (!rs.all_kept) {
+    launch_gather_int(c->inv.p, rs.pair_src.p, cnt, rs.pair_slot.p, s);
+    launch_gather_int(rs.tgt_of_orig.p, rs.pair_src.p, cnt, rs.pair_tgt.p, s);
+  }
   bool have = false;
   float Tbest[16];
   unsigned int inl = 0;
@@ -802,7 +816,7 @@ int ransac_icp(pclmi_icp_ctx *c, RansacScratch &rs, const pclmi_icp_params *p, i
   // mask keep_slot): coalesced, where the pair list in original-source order is a random gather; rs.flags comes back
   // indexed the same way
   const RansacBulk bulk{rs.keep_slot.p, rows, c->nn_slot.p, n};
-  RC(ransac_core(rs.rd, c->pts.p, rs.pair_slot.p, cloud, rs.pair_tgt.p, cnt, p->ransac_outlier_threshold,
+  RC(ransac_core(rs.rd, c->pts.p, rs.slot_of_pair(c), cloud, rs.tgt_of_pair(), cnt, p->ransac_outlier_threshold,
                  p->ransac_iterations, rs.flags.p, s, &have, Tbest, &inl, nullptr, &bulk));
   PCLMI_CHECK(cnt_check == cnt, PCLMI_ERR_HIP, "internal: the step counted %d pairs, the pair list holds %d", cnt,
               cnt_check);
@@ -986,8 +1000,8 @@ int align_core(const pclmi_icp_params *p, const pclmi_tree *target, const float 
         solve_sums = rsums;  // pair sums of the inliers only
       }
       if (obs.fn) {  // the pairs the estimator is about to get (icp.hpp:130-149)
-        if (ninl >= 0) launch_gather_u8(rs.flags.p, rs.pair_slot.p, (size_t)cnt, rs.flags_pos.p, c->stream);
-        rc = ninl >= 0 ? obs.pairs_from_inliers(c, rs.pair_src.p, rs.pair_tgt.p, rs.flags_pos.p, (size_t)cnt)
+        if (ninl >= 0) launch_gather_u8(rs.flags.p, rs.slot_of_pair(c), (size_t)cnt, rs.flags_pos.p, c->stream);
+        rc = ninl >= 0 ? obs.pairs_from_inliers(c, rs.src_of_pair(), rs.tgt_of_pair(), rs.flags_pos.p, (size_t)cnt)
                        : obs.pairs_from_flags(c, rs.keep.p, rs.tgt_of_orig.p);
         if (rc) break;
       }

@@ -151,8 +151,9 @@ def test_bun_full_icp_golden(capi, orc, ransac):
     assert abs(fg - fo) <= 1e-12 + 1e-9 * abs(fo)
 
 
-@pytest.mark.parametrize("n,ransac", [(30000, 0), (30000, 1000), (200_000, 0)])
-def test_synthetic_icp_vs_oracle(capi, orc, n, ransac):
+@pytest.mark.parametrize("n,ransac,maxd", [(30000, 0, 3.0), (30000, 1000, 3.0), (200_000, 0, 3.0),
+                                          (30000, 1000, 1e3)])  # 1e3: every source point keeps its pair
+def test_synthetic_icp_vs_oracle(capi, orc, n, ransac, maxd):
     tgt = surface_cloud(n, 41)
     rng = np.random.default_rng(42)
     sel = rng.permutation(n)[: (n * 9) // 10]
@@ -161,12 +162,12 @@ def test_synthetic_icp_vs_oracle(capi, orc, n, ransac):
     tt = capi.Tree(tgt)
     p = capi.icp_default_params()
     p.max_iterations = 12
-    p.max_correspondence_distance = 3.0
+    p.max_correspondence_distance = maxd
     p.ransac_iterations = ransac
     p.ransac_outlier_threshold = 0.5
     rc, T, out, st = capi.icp_align(tt, src, p)
     po = orc.icp_default_params()
-    po.max_iterations, po.max_correspondence_distance = 12, 3.0
+    po.max_iterations, po.max_correspondence_distance = 12, maxd
     po.ransac_iterations, po.ransac_outlier_threshold = ransac, 0.5
     # the 1e-5 bar is against the reference estimator instantiated with Scalar = double
     # (transformation_estimation_svd.h:57); its fp32 instantiation is itself only accurate to
@@ -176,6 +177,7 @@ def test_synthetic_icp_vs_oracle(capi, orc, n, ransac):
     assert rc == 0 and rco == 0
     assert st.iterations == sto.iterations == 12
     assert st.last_correspondences == sto.last_correspondences
+    assert maxd < 100 or st.last_correspondences == len(src)
     assert np.abs(T - To).max() <= T_TOL, np.abs(T - To).max()
     po.svd_scalar_double = 0
     rco, To32, outo, sto = orc.icp_align(src, tgt, po, nthreads=8)
