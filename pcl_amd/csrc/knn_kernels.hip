@@ -42,6 +42,9 @@
 #define PCLMI_RETAIN 1
 #endif
 // epilogue with one gather per buffered candidate (knn_finish); 0 = filter, then gather the survivors again
+#ifndef PCLMI_NT_STORES
+#define PCLMI_NT_STORES 0
+#endif
 #ifndef PCLMI_LEAF_RETEST
 #define PCLMI_LEAF_RETEST 0
 #endif
@@ -127,7 +130,9 @@ __device__ __forceinline__ int compact_index_buffer(unsigned int (*buf)[64], con
 #pragma unroll
     for (int u = 0; u < 8; ++u) id[u] = buf[min(e + u, C - 1)][lane];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) p[u] = (e + u < cnt) ? cloud[id[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
+    // (unconditional loads through a safe index: a load under a lane condition becomes a branch with its own
+    // s_waitcnt, and the eight gathers run one after the other instead of together)
+    for (int u = 0; u < 8; ++u) p[u] = cloud[(e + u < cnt) ? id[u] : 0u];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const float d = sq3(qx - p[u].x, qy - p[u].y, qz - p[u].z);
@@ -161,7 +166,7 @@ __device__ __forceinline__ int compact_index_buffer(unsigned int (*buf)[64], con
     for (int j = 0; j < K; ++j) sl[j] = buf[min(j, C - 1)][lane];
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-      const float4 p = (j < n) ? cloud[sl[j]] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 p = cloud[(j < n) ? sl[j] : 0u];
       dist_out[j] = sq3(qx - p.x, qy - p.y, qz - p.z);
       idx_out[j] = __float_as_uint(p.w);
     }
@@ -197,7 +202,7 @@ __device__ __forceinline__ void knn_finish(unsigned int (*buf)[64], const float4
       float4 p[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u)
-        p[u] = (e0 + u < C && e0 + u < cnt) ? cloud[id[e0 + u < C ? e0 + u : 0]] : make_float4(0.f, 0.f, 0.f, 0.f);
+        p[u] = cloud[(e0 + u < C && e0 + u < cnt) ? id[e0 + u < C ? e0 + u : 0] : 0u];  // safe index: all eight in flight
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const float d = sq3(qx - p[u].x, qy - p[u].y, qz - p[u].z);
@@ -245,12 +250,21 @@ __device__ __forceinline__ void knn_finish(unsigned int (*buf)[64], const float4
     if (wide) {
 #pragma unroll
       for (int j = 0; j + 3 < K; j += 4) {
-        reinterpret_cast<int4 *>(oi)[j / 4] =
-            make_int4((int)(unsigned int)key[j], (int)(unsigned int)key[j + 1], (int)(unsigned int)key[j + 2],
-                      (int)(unsigned int)key[j + 3]);
-        reinterpret_cast<float4 *>(od)[j / 4] =
-            make_float4(__uint_as_float((unsigned int)(key[j] >> 32)), __uint_as_float((unsigned int)(key[j + 1] >> 32)),
-                        __uint_as_float((unsigned int)(key[j + 2] >> 32)), __uint_as_float((unsigned int)(key[j + 3] >> 32)));
+        typedef int i4v __attribute__((ext_vector_type(4)));
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const i4v vi = {(int)(unsigned int)key[j], (int)(unsigned int)key[j + 1], (int)(unsigned int)key[j + 2],
+                        (int)(unsigned int)key[j + 3]};
+        const f4v vd = {__uint_as_float((unsigned int)(key[j] >> 32)), __uint_as_float((unsigned int)(key[j + 1] >> 32)),
+                        __uint_as_float((unsigned int)(key[j + 2] >> 32)), __uint_as_float((unsigned int)(key[j + 3] >> 32))};
+#if PCLMI_NT_STORES
+        // streaming stores: the 128 bytes per query are written once and not read here again - they should not push
+        // the tree out of the XCD's L2
+        __builtin_nontemporal_store(vi, reinterpret_cast<i4v *>(oi) + j / 4);
+        __builtin_nontemporal_store(vd, reinterpret_cast<f4v *>(od) + j / 4);
+#else
+        reinterpret_cast<i4v *>(oi)[j / 4] = vi;
+        reinterpret_cast<f4v *>(od)[j / 4] = vd;
+#endif
       }
     } else {
 #pragma unroll
@@ -301,7 +315,7 @@ __device__ __forceinline__ void normals_finish(unsigned int (*buf)[64], const fl
     float4 p[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u)
-      p[u] = (j0 + u < K && j0 + u < cnt) ? cloud[buf[min(j0 + u, C - 1)][lane]] : make_float4(0.f, 0.f, 0.f, 0.f);
+      p[u] = cloud[(j0 + u < K && j0 + u < cnt) ? buf[min(j0 + u, C - 1)][lane] : 0u];  // safe index: all eight in flight
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       if (j0 + u >= K) continue;

@@ -182,7 +182,7 @@ struct MomentAcc {
       float4 p[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u)
-        p[u] = (e + u < cnt) ? rows[buf[min(e + u, RN_C - 1)][lane]] : make_float4(0.f, 0.f, 0.f, 0.f);
+        p[u] = rows[(e + u < cnt) ? buf[min(e + u, RN_C - 1)][lane] : 0u];  // safe index: the eight gathers fly together
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         if (e + u < cnt) {
