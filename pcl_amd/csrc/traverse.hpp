@@ -490,11 +490,11 @@ __device__ __forceinline__ void lane_start_at_leaf(const TreeView &t, float qx, 
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      if (id[u]) {
-        const float *bp = t.box + (size_t)(id[u] ^ 1) * 8;  // the sibling's box
-        a[u] = *reinterpret_cast<const float4 *>(bp);
-        b[u] = *reinterpret_cast<const float2 *>(bp + 4);
-      }
+      // unconditional loads (a finished lane re-reads the root's box): under `if (id[u])` each load becomes a branch
+      // with its own s_waitcnt and the four levels are fetched one after the other
+      const float *bp = t.box + (size_t)(id[u] ? (id[u] ^ 1) : 1) * 8;  // the sibling's box
+      a[u] = *reinterpret_cast<const float4 *>(bp);
+      b[u] = *reinterpret_cast<const float2 *>(bp + 4);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
