@@ -42,6 +42,9 @@
 #define PCLMI_RETAIN 1
 #endif
 // epilogue with one gather per buffered candidate (knn_finish); 0 = filter, then gather the survivors again
+#ifndef PCLMI_ONE_GATHER_MIN_K
+#define PCLMI_ONE_GATHER_MIN_K 16
+#endif
 #ifndef PCLMI_NT_STORES
 #define PCLMI_NT_STORES 0
 #endif
@@ -182,7 +185,7 @@ __device__ __forceinline__ void knn_finish(unsigned int (*buf)[64], const float4
                                            float *__restrict__ out_d2) {
   const float qx = lq.x, qy = lq.y, qz = lq.z;
   unsigned long long key[K];
-  if constexpr (PCLMI_FINISH_ONE_GATHER && K >= 16 && C / 2 >= K) {
+  if constexpr (PCLMI_FINISH_ONE_GATHER && K >= PCLMI_ONE_GATHER_MIN_K && C / 2 >= K) {
   // ---- final: ONE gather per buffered candidate (K >= 16; below that the two-pass form is faster: 0.29 vs 0.26 ms
   // per 1M queries at K = 2, 0.41 vs 0.39 at K = 8, but 0.609 vs 0.622 at K = 16, 1.34 vs 1.36 at K = 32).  All bucket slots of the lane's buffer are read into registers
   // first, so the buffer's own LDS rows can take the survivors' (d2, index) keys (two rows per key) while the rows are
