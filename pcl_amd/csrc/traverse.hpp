@@ -23,6 +23,10 @@ typedef const f16v __attribute__((address_space(4))) *cgrp_ptr;   // 64-byte lin
 #ifndef PCLMI_ASM_MIN
 #define PCLMI_ASM_MIN 1
 #endif
+// pre-pass list building by sorting network + bitonic merge (K >= 16) instead of the insertion chain
+#ifndef PCLMI_PREPASS_SORT
+#define PCLMI_PREPASS_SORT 1
+#endif
 #ifndef PCLMI_PREPASS_DESCENT2
 #define PCLMI_PREPASS_DESCENT2 1
 #endif
@@ -102,6 +106,44 @@ __device__ __forceinline__ void list_insert(float (&a)[K], float d) {
 #endif
 }
 
+// Per-lane list building for the pre-pass, where EVERY lane has 16 new distances per bucket: sort the bucket's
+// distances with a 63-exchange network (Batcher's odd-even merge sort), keep the K smallest of list and bucket with a
+// half-cleaner (a[K-16+i] = min(a[K-16+i], b[15-i]): a bitonic sequence) and sort that with the log2(K) stages of a
+// bitonic merger.  K = 16: 286 instructions per bucket instead of the chain's 272 + ..., see lane_bound_list.
+__device__ __forceinline__ void exchange_asc(float &x, float &y) {  // x <- min, y <- max (bare instructions: no NaNs here)
+  float lo, hi;
+  asm("v_min_f32 %0, %1, %2" : "=v"(lo) : "v"(x), "v"(y));
+  asm("v_max_f32 %0, %1, %2" : "=v"(hi) : "v"(x), "v"(y));
+  x = lo;
+  y = hi;
+}
+
+__device__ __forceinline__ void sort16_asc(float (&b)[16]) {
+  constexpr unsigned char net[63][2] = {
+      {0, 1},   {2, 3},   {4, 5},   {6, 7},   {8, 9},   {10, 11}, {12, 13}, {14, 15}, {0, 2},   {1, 3},   {4, 6},
+      {5, 7},   {8, 10},  {9, 11},  {12, 14}, {13, 15}, {1, 2},   {5, 6},   {9, 10},  {13, 14}, {0, 4},   {1, 5},
+      {2, 6},   {3, 7},   {8, 12},  {9, 13},  {10, 14}, {11, 15}, {2, 4},   {3, 5},   {10, 12}, {11, 13}, {1, 2},
+      {3, 4},   {5, 6},   {9, 10},  {11, 12}, {13, 14}, {0, 8},   {1, 9},   {2, 10},  {3, 11},  {4, 12},  {5, 13},
+      {6, 14},  {7, 15},  {4, 8},   {5, 9},   {6, 10},  {7, 11},  {2, 4},   {3, 5},   {6, 8},   {7, 9},   {10, 12},
+      {11, 13}, {1, 2},   {3, 4},   {5, 6},   {7, 8},   {9, 10},  {11, 12}, {13, 14}};
+#pragma unroll
+  for (int c = 0; c < 63; ++c) exchange_asc(b[net[c][0]], b[net[c][1]]);
+}
+
+// a (ascending, K >= 16 a power of two) <- the K smallest of a and b (ascending), ascending
+template <int K>
+__device__ __forceinline__ void list_merge16(float (&a)[K], const float (&b)[16]) {
+  static_assert(K >= 16 && (K & (K - 1)) == 0, "power of two");
+#pragma unroll
+  for (int i = 0; i < 16; ++i) asm("v_min_f32 %0, %0, %1" : "+v"(a[K - 16 + i]) : "v"(b[15 - i]));
+#pragma unroll
+  for (int d = K / 2; d >= 1; d >>= 1) {
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+      if ((i & d) == 0) exchange_asc(a[i], a[i + d]);
+  }
+}
+
 // wave-uniform stack kept in the lanes of one VGPR
 struct LaneStack {
   int v;
@@ -172,10 +214,10 @@ __device__ __forceinline__ void lane_bound_list(const TreeView &t, float qx, flo
                                                 int &home) {
   const int M = t.M;
   int node = 1;
+  const f2v q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
 #if PCLMI_PREPASS_DESCENT2
   // two levels per dependent load (the four grandchildren boxes are two adjacent 64-byte lines), packed box distances:
   // towards the nearest grandchild.  Any bucket near the query will do - the walk only wants a finite starting bound.
-  const f2v q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
   while (2 * node + 1 < M) {
     const float4 *b = reinterpret_cast<const float4 *>(t.box + (size_t)node * 32);
     const float4 a0 = b[0], a1 = b[1], a2 = b[2], a3 = b[3], c0 = b[4], c1 = b[5], c2 = b[6], c3 = b[7];
@@ -207,13 +249,23 @@ __device__ __forceinline__ void lane_bound_list(const TreeView &t, float qx, flo
     const int bn = first + s;
     if (bn < M || bn > 2 * M - 1) continue;
     const float4 *rec = reinterpret_cast<const float4 *>(t.leaf + (size_t)(bn - M) * (4 * L));
+    float b[L];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       const float4 X = rec[g * 4 + 0], Y = rec[g * 4 + 1], Z = rec[g * 4 + 2];
-      list_insert<K>(a, sq3(qx - X.x, qy - Y.x, qz - Z.x));
-      list_insert<K>(a, sq3(qx - X.y, qy - Y.y, qz - Z.y));
-      list_insert<K>(a, sq3(qx - X.z, qy - Y.z, qz - Z.z));
-      list_insert<K>(a, sq3(qx - X.w, qy - Y.w, qz - Z.w));
+      const f2v d01 = sq3_pk(q2x - f2v{X.x, X.y}, q2y - f2v{Y.x, Y.y}, q2z - f2v{Z.x, Z.y});
+      const f2v d23 = sq3_pk(q2x - f2v{X.z, X.w}, q2y - f2v{Y.z, Y.w}, q2z - f2v{Z.z, Z.w});
+      b[4 * g + 0] = d01.x;
+      b[4 * g + 1] = d01.y;
+      b[4 * g + 2] = d23.x;
+      b[4 * g + 3] = d23.y;
+    }
+    if constexpr (PCLMI_PREPASS_SORT && K >= 16 && (K & (K - 1)) == 0 && L == 16) {
+      sort16_asc(b);
+      list_merge16<K>(a, b);
+    } else {
+#pragma unroll
+      for (int j = 0; j < L; ++j) list_insert<K>(a, b[j]);
     }
   }
 }
