@@ -90,23 +90,15 @@ using namespace dev;
 
 template <int N>
 __device__ __forceinline__ void sort_keys(unsigned long long (&k)[N]) {
-  // bitonic sorting network on N (power of two) 64-bit keys held in registers
+  // sorting network on N (power of two) 64-bit keys held in registers: Batcher's odd-even merge sort, a fifth fewer
+  // exchanges than the bitonic sorter and all of them in one direction
+  constexpr OddEvenMergeNet<N> net{};
 #pragma unroll
-  for (int size = 2; size <= N; size <<= 1) {
-#pragma unroll
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-#pragma unroll
-      for (int i = 0; i < N; ++i) {
-        int j = i ^ stride;
-        if (j > i) {
-          bool up = (i & size) == 0;
-          unsigned long long x = k[i], y = k[j];
-          bool sw = up ? (y < x) : (x < y);
-          k[i] = sw ? y : x;
-          k[j] = sw ? x : y;
-        }
-      }
-    }
+  for (int c = 0; c < net.n; ++c) {
+    const unsigned long long x = k[net.lo[c]], y = k[net.hi[c]];
+    const bool sw = y < x;
+    k[net.lo[c]] = sw ? y : x;
+    k[net.hi[c]] = sw ? x : y;
   }
 }
 

@@ -107,7 +107,7 @@ __device__ __forceinline__ void list_insert(float (&a)[K], float d) {
 }
 
 // Per-lane list building for the pre-pass, where EVERY lane has 16 new distances per bucket: sort the bucket's
-// distances with a 63-exchange network (Batcher's odd-even merge sort), keep the K smallest of list and bucket with a
+// distances with a 63-exchange network (Batcher's odd-even merge sort, OddEvenMergeNet), keep the K smallest of list and bucket with a
 // half-cleaner (a[K-16+i] = min(a[K-16+i], b[15-i]): a bitonic sequence) and sort that with the log2(K) stages of a
 // bitonic merger.  K = 16: 286 instructions per bucket instead of the chain's 272 + ..., see lane_bound_list.
 __device__ __forceinline__ void exchange_asc(float &x, float &y) {  // x <- min, y <- max (bare instructions: no NaNs here)
@@ -118,16 +118,30 @@ __device__ __forceinline__ void exchange_asc(float &x, float &y) {  // x <- min,
   y = hi;
 }
 
+// Batcher's odd-even merge sort for N = 2^m inputs as a list of compare-exchange pairs (i < j: the smaller value goes
+// to i), generated at compile time: 63 exchanges for 16 inputs, 191 for 32, 543 for 64 (a bitonic sorter: 80 / 240 / 672).
+template <int N>
+struct OddEvenMergeNet {
+  static_assert(N >= 2 && N <= 64 && (N & (N - 1)) == 0, "power of two");
+  unsigned char lo[N * 9], hi[N * 9];
+  int n;
+  constexpr OddEvenMergeNet() : lo{}, hi{}, n(0) {
+    for (int p = 1; p < N; p <<= 1)
+      for (int k = p; k >= 1; k >>= 1)
+        for (int j = k % p; j + k < N; j += 2 * k)
+          for (int i = 0; i < k && i + j + k < N; ++i)
+            if ((i + j) / (2 * p) == (i + j + k) / (2 * p)) {
+              lo[n] = (unsigned char)(i + j);
+              hi[n] = (unsigned char)(i + j + k);
+              ++n;
+            }
+  }
+};
+
 __device__ __forceinline__ void sort16_asc(float (&b)[16]) {
-  constexpr unsigned char net[63][2] = {
-      {0, 1},   {2, 3},   {4, 5},   {6, 7},   {8, 9},   {10, 11}, {12, 13}, {14, 15}, {0, 2},   {1, 3},   {4, 6},
-      {5, 7},   {8, 10},  {9, 11},  {12, 14}, {13, 15}, {1, 2},   {5, 6},   {9, 10},  {13, 14}, {0, 4},   {1, 5},
-      {2, 6},   {3, 7},   {8, 12},  {9, 13},  {10, 14}, {11, 15}, {2, 4},   {3, 5},   {10, 12}, {11, 13}, {1, 2},
-      {3, 4},   {5, 6},   {9, 10},  {11, 12}, {13, 14}, {0, 8},   {1, 9},   {2, 10},  {3, 11},  {4, 12},  {5, 13},
-      {6, 14},  {7, 15},  {4, 8},   {5, 9},   {6, 10},  {7, 11},  {2, 4},   {3, 5},   {6, 8},   {7, 9},   {10, 12},
-      {11, 13}, {1, 2},   {3, 4},   {5, 6},   {7, 8},   {9, 10},  {11, 12}, {13, 14}};
+  constexpr OddEvenMergeNet<16> net{};
 #pragma unroll
-  for (int c = 0; c < 63; ++c) exchange_asc(b[net[c][0]], b[net[c][1]]);
+  for (int c = 0; c < net.n; ++c) exchange_asc(b[net.lo[c]], b[net.hi[c]]);
 }
 
 // a (ascending, K >= 16 a power of two) <- the K smallest of a and b (ascending), ascending
