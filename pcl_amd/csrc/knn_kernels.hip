@@ -1010,7 +1010,12 @@ int launch_morton_order(const pclmi_tree *t, Workspace *w, const float *d_q, siz
       nb_hi = tube_p ? tube_p * tube_p : gy * gz;
     }
   }
-  int ntiles = (int)((nq + 4095) / 4096);
+  static const int tile_env = [] {
+    const char *e = getenv("PCLMI_TILE");  // development knob: queries per tile of the two-level sort
+    return e ? atoi(e) : 4096;
+  }();
+  const int tile_q = tile_env >= 1024 ? tile_env : 4096;
+  int ntiles = (int)((nq + tile_q - 1) / tile_q);
   ntiles = ntiles > 512 ? 512 : ntiles;
   const int tile_size = (int)((nq + ntiles - 1) / ntiles);
   int rc = w->ensure_queries(nq, stable ? 1 : two_level ? (size_t)nb_hi * ntiles + 1 : nbins);
