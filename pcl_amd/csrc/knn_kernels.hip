@@ -519,13 +519,13 @@ template <int K, int C, bool NRM = false>
 __global__ __launch_bounds__(64) void knn_lane_ix_kernel(TreeView t, const float *__restrict__ q, int q_stride_f,
                                                          const int *__restrict__ order, int nq, int levels, int k_out,
                                                          int *__restrict__ out_idx, float *__restrict__ out_d2,
-                                                         float vpx, float vpy, float vpz) {
+                                                         float vpx, float vpy, float vpz, int qpw) {
   static_assert(C >= K + L + 8, "buffer must hold the K best plus one bucket of appends");
   extern __shared__ float far_lds[];  // levels x 64 floats
   __shared__ unsigned int lds[C][64];
   const int lane = threadIdx.x & 63;
   LaneQuery lq;
-  if (!load_lane_query<1>(q, q_stride_f, order, nq, lq)) return;
+  if (!load_lane_query<1>(q, q_stride_f, order, nq, lq, qpw)) return;
   const float qx = lq.x, qy = lq.y, qz = lq.z;
   unsigned int(*buf)[64] = lds;
   const float4 *cloud = reinterpret_cast<const float4 *>(t.slot);
@@ -600,11 +600,11 @@ template <int WPB>
 __global__ __launch_bounds__(64 * WPB) void knn1_lane_kernel(TreeView t, const float *__restrict__ q,
                                                               int q_stride_f, const int *__restrict__ order,
                                                               int nq, int levels, int *__restrict__ out_idx,
-                                                              float *__restrict__ out_d2) {
+                                                              float *__restrict__ out_d2, int qpw) {
   extern __shared__ float far_lds[];
   const int lane = threadIdx.x & 63;
   LaneQuery lq;
-  if (!load_lane_query<WPB>(q, q_stride_f, order, nq, lq)) return;
+  if (!load_lane_query<WPB>(q, q_stride_f, order, nq, lq, qpw)) return;
   int best_slot;
   const unsigned long long best =
       lane_nearest(t, lq.x, lq.y, lq.z, lq.searchable, __builtin_inff(),
@@ -1100,14 +1100,15 @@ template <int K, int C>
 static void launch_lane_ix(const pclmi_tree *t, const float *d_q, size_t nq, size_t qsf, const int32_t *order,
                            int k_eff, int32_t *d_idx, float *d_d2, hipStream_t s, const float *vp = nullptr) {
   const int levels = lane_nearest_levels(t->M);
-  const unsigned blocks = (((unsigned)((nq + 63) / 64)) + 7) & ~7u;
+  const int qpw = lane_queries_per_wave(nq, K <= 16 ? 2048 : 1024);
+  const unsigned blocks = (((unsigned)((nq + qpw - 1) / qpw)) + 7) & ~7u;
   const size_t lds = (size_t)levels * 64 * sizeof(float);
   if (vp)
     hipLaunchKernelGGL((knn_lane_ix_kernel<K, C, true>), dim3(blocks), dim3(64), lds, s, t->view(), d_q, (int)qsf, order,
-                       (int)nq, levels, k_eff, d_idx, d_d2, vp[0], vp[1], vp[2]);
+                       (int)nq, levels, k_eff, d_idx, d_d2, vp[0], vp[1], vp[2], qpw);
   else
     hipLaunchKernelGGL((knn_lane_ix_kernel<K, C, false>), dim3(blocks), dim3(64), lds, s, t->view(), d_q, (int)qsf, order,
-                       (int)nq, levels, k_eff, d_idx, d_d2, 0.f, 0.f, 0.f);
+                       (int)nq, levels, k_eff, d_idx, d_d2, 0.f, 0.f, 0.f, qpw);
 }
 
 // sparse batch: the per-lane kernels (measured crossover); PCLMI_KNN=union / lane forces one
@@ -1192,8 +1193,11 @@ int launch_knn(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, s
     const bool per_lane = forced ? forced == 2 : nq * 2 < t->n;
     if (per_lane) {
       const int levels = lane_nearest_levels(t->M);
+      const int qpw = lane_queries_per_wave(nq, 2048);
+      waves = (unsigned)((nq + qpw - 1) / qpw);
+      blocks = ((waves + WPB - 1) / WPB + 7) & ~7u;
       hipLaunchKernelGGL((knn1_lane_kernel<WPB>), dim3(blocks), dim3(64 * WPB), (size_t)WPB * levels * 64 * sizeof(float),
-                         s, t->view(), d_q, (int)qsf, order, (int)nq, levels, d_idx, d_d2);
+                         s, t->view(), d_q, (int)qsf, order, (int)nq, levels, d_idx, d_d2, qpw);
     } else {
       hipLaunchKernelGGL((knn1_union_kernel<WPB>), dim3(blocks), dim3(64 * WPB), 0, s, t->view(), d_q, (int)qsf,
                          order, (int)nq, d_idx, d_d2);

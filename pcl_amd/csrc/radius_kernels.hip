@@ -117,12 +117,12 @@ __global__ __launch_bounds__(64) void radius_lane_kernel(TreeView t, const float
                                                          const int *__restrict__ order, int nq, int levels, float r2,
                                                          float tau_r, int by_index, unsigned int *__restrict__ counts,
                                                          const u64 *__restrict__ offsets, u64 *__restrict__ keys,
-                                                         unsigned int *__restrict__ n_over) {
+                                                         unsigned int *__restrict__ n_over, int qpw) {
   constexpr bool FILL = MODE == 1;
   extern __shared__ float far_lds[];  // levels x 64 floats
   const int lane = threadIdx.x & 63;
   LaneQuery lq;
-  if (!load_lane_query<1>(q, q_stride_f, order, nq, lq)) return;
+  if (!load_lane_query<1>(q, q_stride_f, order, nq, lq, qpw)) return;
   const float qx = lq.x, qy = lq.y, qz = lq.z;
   unsigned int cnt = 0;
   u64 *out = nullptr;
@@ -272,12 +272,12 @@ __global__ __launch_bounds__(64 * RN_WPB) void radius_normals_union_kernel(TreeV
 __global__ __launch_bounds__(64) void radius_normals_lane_kernel(TreeView t, const float *__restrict__ q, int q_stride_f,
                                                                  const int *__restrict__ order, int nq, int levels,
                                                                  float r2, float tau_r, float vpx, float vpy, float vpz,
-                                                                 float4 *__restrict__ out) {
+                                                                 float4 *__restrict__ out, int qpw) {
   extern __shared__ float far_lds[];  // levels x 64 floats
   __shared__ unsigned int buf[RN_C][64];
   const int lane = threadIdx.x & 63;
   LaneQuery lq;
-  if (!load_lane_query<1>(q, q_stride_f, order, nq, lq)) return;
+  if (!load_lane_query<1>(q, q_stride_f, order, nq, lq, qpw)) return;
   const float qx = lq.x, qy = lq.y, qz = lq.z;
   const float4 *rows = reinterpret_cast<const float4 *>(t.slot);
   int cnt = 0;
@@ -317,8 +317,11 @@ void launch_radius_traversal(const pclmi_tree *t, bool per_lane, const float *d_
   const unsigned waves = (unsigned)((nq + 63) / 64);
   if (per_lane) {
     const int levels = lane_nearest_levels(t->M);
-    hipLaunchKernelGGL((radius_lane_kernel<MODE>), dim3((waves + 7) & ~7u), dim3(64), (size_t)levels * 64 * sizeof(float),
-                       s, t->view(), d_q, qsf, order, nq, levels, r2, tau_r, by_index, counts, offsets, keys, n_over);
+    const int qpw = lane_queries_per_wave((size_t)nq, 2048);
+    const unsigned lane_waves = (unsigned)((nq + qpw - 1) / qpw);
+    hipLaunchKernelGGL((radius_lane_kernel<MODE>), dim3((lane_waves + 7) & ~7u), dim3(64),
+                       (size_t)levels * 64 * sizeof(float), s, t->view(), d_q, qsf, order, nq, levels, r2, tau_r, by_index,
+                       counts, offsets, keys, n_over, qpw);
   } else {
     const unsigned blocks = ((waves + R_WPB - 1) / R_WPB + 7) & ~7u;
     hipLaunchKernelGGL((radius_union_kernel<MODE>), dim3(blocks), dim3(64 * R_WPB), 0, s, t->view(), d_q, qsf, order, nq,
@@ -687,9 +690,11 @@ int radius_normals_dev(const pclmi_tree *t, Workspace *w, const float *d_q, size
   TimingScope ts(PCLMI_TIMER_RADIUS, s);
   if (per_lane) {
     const int levels = lane_nearest_levels(t->M);
-    hipLaunchKernelGGL(radius_normals_lane_kernel, dim3((waves + 7) & ~7u), dim3(64), (size_t)levels * 64 * sizeof(float),
-                       s, t->view(), d_q, (int)qsf, order, (int)nq, levels, r2, tau_r, vp[0], vp[1], vp[2],
-                       reinterpret_cast<float4 *>(d_out));
+    const int qpw = lane_queries_per_wave(nq, 2048);
+    const unsigned lane_waves = (unsigned)((nq + qpw - 1) / qpw);
+    hipLaunchKernelGGL(radius_normals_lane_kernel, dim3((lane_waves + 7) & ~7u), dim3(64),
+                       (size_t)levels * 64 * sizeof(float), s, t->view(), d_q, (int)qsf, order, (int)nq, levels, r2, tau_r,
+                       vp[0], vp[1], vp[2], reinterpret_cast<float4 *>(d_out), qpw);
   } else {
     const unsigned blocks = ((waves + RN_WPB - 1) / RN_WPB + 7) & ~7u;
     hipLaunchKernelGGL(radius_normals_union_kernel, dim3(blocks), dim3(64 * RN_WPB), 0, s, t->view(), d_q, (int)qsf,

@@ -183,18 +183,20 @@ struct LaneQuery {
   bool searchable;  // ... and that query is finite
 };
 
+// qpw: queries per wavefront (lanes qpw..63 stay idle).  Small batches of the per-lane kernels are spread over more
+// wavefronts than they would fill: a wavefront's time is the LONGEST of its lanes' walks, and an empty GPU has slots.
 template <int WPB>
 __device__ __forceinline__ bool load_lane_query(const float *__restrict__ q, int q_stride_f,
-                                                const int *__restrict__ order, int nq, LaneQuery &o) {
+                                                const int *__restrict__ order, int nq, LaneQuery &o, int qpw = 64) {
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
   // blocks b, b+8, b+16 ... share an XCD (and its L2): give each XCD one contiguous range of the
   // sorted queries so that its L2 holds one part of the tree.  (Placement only affects speed.)
   const int per = (gridDim.x + 7) >> 3;
   const int blk = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-  const int slot = (blk * WPB + wib) * 64 + lane;
+  const int slot = (blk * WPB + wib) * qpw + lane;
   if (__builtin_amdgcn_readfirstlane(slot) >= nq) return false;  // whole wave past the end
-  o.alive = slot < nq;
+  o.alive = slot < nq && lane < qpw;
   o.slot = slot;
   o.qi = o.alive ? (order ? order[slot] : slot) : 0;
   o.x = o.y = o.z = __builtin_nanf("");  // dead lanes: every comparison is false
@@ -210,6 +212,20 @@ __device__ __forceinline__ bool load_lane_query(const float *__restrict__ q, int
   o.searchable = o.alive && isfinite(o.x) && isfinite(o.y) && isfinite(o.z);
   if (!o.searchable) o.x = o.y = o.z = __builtin_nanf("");
   return true;
+}
+
+// Queries per wavefront of a per-lane kernel: 64 once the batch fills `resident` wavefronts (what the GPU holds at a
+// time), else the power of two that spreads it over about that many (see load_lane_query).  PCLMI_LANE_WAVES overrides
+// `resident` (development knob; 0 = always 64).
+inline int lane_queries_per_wave(size_t nq, int resident) {
+  static const int env = [] {
+    const char *e = getenv("PCLMI_LANE_WAVES");
+    return e ? atoi(e) : -1;
+  }();
+  if (env >= 0) resident = env;
+  int qpw = 64;
+  while (qpw > 1 && (nq + qpw / 2 - 1) / (qpw / 2) <= (size_t)resident) qpw >>= 1;
+  return qpw;
 }
 
 // Per-lane pre-pass: walk down to a nearby bucket (towards the nearer child box), scan it and its
