@@ -42,6 +42,12 @@
 #define PCLMI_RETAIN 1
 #endif
 // epilogue with one gather per buffered candidate (knn_finish); 0 = filter, then gather the survivors again
+// the per-lane (sparse-batch) kernel starts from an empty list instead of the pre-pass: its nearest-first descent
+// reaches the query's own bucket anyway, and the pre-pass's second descent is pure latency there (k = 16: one query
+// 33.7 -> 31.0 us, 16k queries 124 -> 118, 150k 211 -> 202; k = 32: 58.7 -> 49.7, 198 -> 190, 434 -> 421)
+#ifndef PCLMI_LANE_NOPREPASS
+#define PCLMI_LANE_NOPREPASS 1
+#endif
 #ifndef PCLMI_ONE_GATHER_MIN_K
 #define PCLMI_ONE_GATHER_MIN_K 16
 #endif
@@ -529,12 +535,17 @@ __global__ __launch_bounds__(64) void knn_lane_ix_kernel(TreeView t, const float
   const float qx = lq.x, qy = lq.y, qz = lq.z;
   unsigned int(*buf)[64] = lds;
   const float4 *cloud = reinterpret_cast<const float4 *>(t.slot);
-  // the pre-pass list is kept, as in the union kernel: a[] starts as the K smallest distances of the home buckets, and
-  // in a home bucket the lane appends what is within its bound but inserts nothing
+  // (with PCLMI_LANE_NOPREPASS=0) the pre-pass list is kept, as in the union kernel: a[] starts as the K smallest
+  // distances of the home buckets, and in a home bucket the lane appends what is within its bound but inserts nothing
   float a[K];
   int home = -0x40000000;
   if (lq.searchable) {
+#if PCLMI_LANE_NOPREPASS
+#pragma unroll
+    for (int j = 0; j < K; ++j) a[j] = 3.402823466e+38f;
+#else
     lane_bound_list<K>(t, qx, qy, qz, a, home);
+#endif
   } else {
 #pragma unroll
     for (int j = 0; j < K; ++j) a[j] = -1.f;

@@ -7,6 +7,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import numpy as np
 import torch
 from pcl_amd import capi
+if os.environ.get("PCLMI_LIB"):
+    capi.load_library(os.environ["PCLMI_LIB"])
 
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 n = 1_000_000
