@@ -361,12 +361,12 @@ __global__ __launch_bounds__(64 * WPB)
                                                                  int q_stride_f, const int *__restrict__ order,
                                                                  int nq, int k_out, int *__restrict__ out_idx,
                                                                  float *__restrict__ out_d2, float vpx, float vpy,
-                                                                 float vpz) {
+                                                                 float vpz, int qpw) {
   static_assert(C >= K + 8, "buffer must hold the K best plus two groups of appends");
   __shared__ unsigned int lds[WPB][C][64];
   const int lane = threadIdx.x & 63;
   LaneQuery lq;
-  if (!load_lane_query<WPB>(q, q_stride_f, order, nq, lq)) return;
+  if (!load_lane_query<WPB>(q, q_stride_f, order, nq, lq, qpw)) return;
   const float qx = lq.x, qy = lq.y, qz = lq.z;
   unsigned int(*buf)[64] = lds[threadIdx.x >> 6];
   const float4 *cloud = reinterpret_cast<const float4 *>(t.slot);  // bucket-slot rows (x, y, z, idx bits)
@@ -1095,15 +1095,19 @@ template <int K, int C, int WPB>
 static int launch_union_ix(const pclmi_tree *t, Workspace *, const float *d_q, size_t nq, size_t qsf,
                            const int32_t *order, int k_eff, int32_t *d_idx, float *d_d2, hipStream_t s,
                            const float *vp = nullptr) {
-  unsigned waves = (unsigned)((nq + 63) / 64);
+  // a sparse batch that leaves wavefront slots empty is spread over them, down to one query per wavefront (whose
+  // "union" is then that query's own ball, walked with scalar loads), see load_lane_query: K = 64 has no per-lane
+  // twin, and below that knn_sparse sends batches of up to 4096 queries here
+  const int qpw = (nq * 6 < t->n) ? lane_queries_per_wave(nq, K == 64 ? 1024 : K == 32 ? 2048 : 4096) : 64;
+  unsigned waves = (unsigned)((nq + qpw - 1) / qpw);
   unsigned blocks = (waves + WPB - 1) / WPB;
   blocks = (blocks + 7) & ~7u;
   if (vp)
     hipLaunchKernelGGL((knn_union_ix_kernel<K, C, WPB, true>), dim3(blocks), dim3(64 * WPB), 0, s, t->view(), d_q,
-                       (int)qsf, order, (int)nq, k_eff, d_idx, d_d2, vp[0], vp[1], vp[2]);
+                       (int)qsf, order, (int)nq, k_eff, d_idx, d_d2, vp[0], vp[1], vp[2], qpw);
   else
     hipLaunchKernelGGL((knn_union_ix_kernel<K, C, WPB, false>), dim3(blocks), dim3(64 * WPB), 0, s, t->view(), d_q,
-                       (int)qsf, order, (int)nq, k_eff, d_idx, d_d2, 0.f, 0.f, 0.f);
+                       (int)qsf, order, (int)nq, k_eff, d_idx, d_d2, 0.f, 0.f, 0.f, qpw);
   return PCLMI_OK;
 }
 
@@ -1132,7 +1136,11 @@ static bool knn_sparse(const pclmi_tree *t, size_t nq) {
     const char *e = getenv("PCLMI_KNN_SPARSE_RATIO");
     return e ? (size_t)atoi(e) : (size_t)6;  // 1M-point target, k = 16: 100k queries lane 0.237 / union 0.282 ms, 250k 0.410 / 0.288
   }();
-  return forced ? forced == 2 : nq * ratio < t->n;
+  // up to 4096 queries the union kernel takes sparse batches too: launch_union_ix gives every query a wavefront of
+  // its own, whose walk is then that one query's, on scalar loads (k = 16, 1M-point target: 1 query 26.8 us against
+  // the per-lane kernel's 31.0, 64 queries 38 / 48, 1024 51 / 60, 4096 75 / 90; 16 384 - four queries per wavefront -
+  // 126 / 119)
+  return forced ? forced == 2 : (nq > 4096 && nq * ratio < t->n);
 }
 
 #define PCLMI_STR2(x) #x
