@@ -594,10 +594,10 @@ __global__ __launch_bounds__(64 * WPB) void knn1_union_kernel(TreeView t, const 
                                                                int q_stride_f,
                                                                const int *__restrict__ order, int nq,
                                                                int *__restrict__ out_idx,
-                                                               float *__restrict__ out_d2) {
+                                                               float *__restrict__ out_d2, int qpw) {
   const int lane = threadIdx.x & 63;
   LaneQuery lq;
-  if (!load_lane_query<WPB>(q, q_stride_f, order, nq, lq)) return;
+  if (!load_lane_query<WPB>(q, q_stride_f, order, nq, lq, qpw)) return;
   const float qx = lq.x, qy = lq.y, qz = lq.z;
   const unsigned long long best = wave_nearest(t, qx, qy, qz, lq.searchable, lane);
   if (lq.alive) {
@@ -1209,7 +1209,10 @@ int launch_knn(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, s
       const char *e = getenv("PCLMI_NN1");
       return !e ? 0 : (e[0] == 'u' ? 1 : (e[0] == 'l' ? 2 : 0));
     }();
-    const bool per_lane = forced ? forced == 2 : nq * 2 < t->n;
+    // Batches of 4..4096 queries take the wave-uniform walk even when sparse: spread one query per wavefront (below),
+    // it walks that query's ball on scalar loads (64 queries 21.7 against 25.8 us, 1024 26.4 / 32.2, 4096 36.6 / 40.1;
+    // a single query 11.6 / 10.4, 16 384 queries 54.9 / 50.2).
+    const bool per_lane = forced ? forced == 2 : (nq * 2 < t->n && (nq > 4096 || nq < 4));
     if (per_lane) {
       const int levels = lane_nearest_levels(t->M);
       const int qpw = lane_queries_per_wave(nq, 2048);
@@ -1218,8 +1221,11 @@ int launch_knn(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, s
       hipLaunchKernelGGL((knn1_lane_kernel<WPB>), dim3(blocks), dim3(64 * WPB), (size_t)WPB * levels * 64 * sizeof(float),
                          s, t->view(), d_q, (int)qsf, order, (int)nq, levels, d_idx, d_d2, qpw);
     } else {
+      const int qpw = (nq * 2 < t->n) ? lane_queries_per_wave(nq, 4096) : 64;  // sparse here: forced, or a small batch
+      waves = (unsigned)((nq + qpw - 1) / qpw);
+      blocks = ((waves + WPB - 1) / WPB + 7) & ~7u;
       hipLaunchKernelGGL((knn1_union_kernel<WPB>), dim3(blocks), dim3(64 * WPB), 0, s, t->view(), d_q, (int)qsf,
-                         order, (int)nq, d_idx, d_d2);
+                         order, (int)nq, d_idx, d_d2, qpw);
     }
   } else if (k_eff <= 32 && knn_sparse(t, nq)) {
     if (k_eff <= 4) launch_lane_ix<4, 32>(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
