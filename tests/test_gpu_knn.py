@@ -77,9 +77,10 @@ def test_grid_ties(capi, orc, k):
 
 @pytest.mark.parametrize("k", [2, 3, 4, 5, 8, 10, 16, 20, 32])
 def test_sparse_batches_take_the_per_lane_kernel(capi, orc, k):
-    """Fewer than a sixth as many queries as target points: knn_lane_ix_kernel (each lane walks for itself).  The
-    same bars as the union kernel: ties on a grid, duplicates beyond a bucket, NaN queries, a ragged last wave - and
-    both kernels must agree on one batch (PCLMI_KNN is read once per process, so the batch sizes pick the kernels)."""
+    """Fewer than a sixth as many queries as target points.  More than 4096 of them: knn_lane_ix_kernel (each lane
+    walks for itself); fewer: the union kernel with the batch spread over the wavefronts, down to one query each.  The
+    same bars as the dense union kernel: ties on a grid, duplicates beyond a bucket, NaN queries, a ragged last wave -
+    and the kernels must agree on one batch (PCLMI_KNN is read once per process, so the batch sizes pick the kernels)."""
     pts = util.grid_cloud()  # 1331 points, many exactly-equal distances
     q = np.concatenate([pts[::13], np.array([[0.01, 0.01, 0.01], [0, 0, 0], [0.05, 0.05, 0.05]], np.float32),
                         pts[:100] + np.float32(0.05)])
@@ -103,6 +104,27 @@ def test_sparse_batches_take_the_per_lane_kernel(capi, orc, k):
     si, sd = tb.knn(sparse, k)
     di, dd = tb.knn(dense, k)
     assert np.array_equal(si, di[:15_001]) and np.array_equal(sd.view(np.int32), dd[:15_001].view(np.int32))
+
+
+@pytest.mark.parametrize("k", [1, 16, 40, 64])
+def test_small_sparse_batches_are_spread_over_the_wavefronts(capi, orc, k):
+    """Sparse batches of 1 .. 4096 queries run with 1, 2, 4 ... queries per wavefront (lane_queries_per_wave), above
+    that the per-lane kernels take over (k <= 32) or the union kernel fills its wavefronts again (k = 33..64): every
+    batch size around those switches must give the oracle's rows, NaN queries included."""
+    pts = util.uniform_cloud(120_000, 71, 0, 100)
+    t = capi.Tree(pts)
+    ot = orc.Tree(pts)
+    allq = util.uniform_cloud(9000, 72, -5, 105)  # some outside the target's box
+    allq[5] = np.nan
+    allq[4090, 1] = np.inf
+    for nq in (1, 2, 3, 5, 63, 64, 65, 1000, 2049, 4095, 4096, 4097, 9000):
+        q = allq[:nq]
+        gi, gd = t.knn(q, k)
+        good = np.isfinite(q).all(axis=1)
+        oi, od = ot.knn(q[good], k, nthreads=8)
+        assert np.array_equal(gi[good], oi) and np.array_equal(gd[good].view(np.int32), od.view(np.int32)), (k, nq)
+        assert (gi[~good] == -1).all() and np.isnan(gd[~good]).all(), (k, nq)
+    t.close()
 
 
 def test_duplicates_and_tiny_clouds(capi, orc):
