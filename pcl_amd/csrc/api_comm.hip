@@ -9,8 +9,12 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <signal.h>
+
 #include <atomic>
+#include <cerrno>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 
@@ -25,14 +29,22 @@ struct pclmi_comm {
   unsigned int *seq = nullptr;
   void *peer[kCommMaxRanks] = {nullptr};  // IPC mappings (nullptr for the own rank)
   bool connected = false;
+  bool dead = false;          // an exchange timed out: the ranks' sequence numbers are out of step for good
+  const char *memory = "?";   // flavour of the mailbox allocation (reported with PCLMI_ERR_COMM)
+  size_t bulk_bytes = 0;      // bulk window behind the mailbox (the pair mask of the sharded RANSAC step)
   double timeout_s = 10.0;
+  static size_t bulk_offset() { return kCommBoxWords * sizeof(unsigned long long) + kCommCtrlBytes; }
   CommView view() const {
     CommView v;
     v.rank = rank;
     v.world = world;
-    for (int p = 0; p < kCommMaxRanks; ++p) v.box[p] = p == rank ? box : (unsigned long long *)peer[p];
+    for (int p = 0; p < kCommMaxRanks; ++p) {
+      v.box[p] = p == rank ? box : (unsigned long long *)peer[p];
+      v.bulk[p] = v.box[p] ? (unsigned long long *)((char *)v.box[p] + bulk_offset()) : nullptr;
+    }
     v.seq = seq;
     v.timeout_ticks = (unsigned long long)(timeout_s * 1e8);  // wall_clock64: 100 MHz
+    v.bulk_cap = (bulk_bytes / sizeof(unsigned long long) / (2 * (size_t)world)) & ~(size_t)1;
     return v;
   }
 };
@@ -40,6 +52,9 @@ struct pclmi_comm {
 namespace pclmi {
 CommView comm_view(const pclmi_comm *c) { return c->view(); }
 int comm_device(const pclmi_comm *c) { return c->device; }
+bool comm_dead(const pclmi_comm *c) { return c->dead; }
+void comm_set_dead(pclmi_comm *c) { c->dead = true; }
+const char *comm_memory(const pclmi_comm *c) { return c->memory; }
 }  // namespace pclmi
 
 namespace {
@@ -82,14 +97,33 @@ int pclmi_comm_begin(int rank, int world, pclmi_comm **out, unsigned char handle
   c->rank = rank;
   c->world = world;
   c->device = dev;
-  const size_t bytes = kCommBoxWords * sizeof(unsigned long long) + 256;
-  // uncached device memory: peers write it over xGMI, the owner polls it; nothing of it may linger in an L2
+  {
+    const char *mb = getenv("PCLMI_COMM_BULK_MB");
+    long v = mb ? atol(mb) : 64;
+    if (v < 0) v = 0;
+    if (v > 4096) v = 4096;
+    c->bulk_bytes = world > 1 ? (size_t)v << 20 : 0;
+  }
+  const size_t bytes = pclmi_comm::bulk_offset() + c->bulk_bytes;
+  // uncached device memory: peers write it over xGMI, the owner polls it; nothing of it may linger in an L2.
+  // Coarse-grained memory (plain hipMalloc) is NOT a fallback: the owner's polling loads are not guaranteed to see
+  // the peers' writes there (intermittent timeouts); PCLMI_COMM_ALLOW_COARSE=1 forces it for experiments.
   hipError_t e = hipExtMallocWithFlags((void **)&c->box, bytes, hipDeviceMallocUncached);
-  if (e != hipSuccess) e = hipExtMallocWithFlags((void **)&c->box, bytes, hipDeviceMallocFinegrained);
-  if (e != hipSuccess) e = hipMalloc((void **)&c->box, bytes);
+  c->memory = "uncached";
+  if (e != hipSuccess) {
+    e = hipExtMallocWithFlags((void **)&c->box, bytes, hipDeviceMallocFinegrained);
+    c->memory = "fine-grained";
+  }
+  if (e != hipSuccess && getenv("PCLMI_COMM_ALLOW_COARSE") && atoi(getenv("PCLMI_COMM_ALLOW_COARSE")) != 0) {
+    e = hipMalloc((void **)&c->box, bytes);
+    c->memory = "coarse-grained (PCLMI_COMM_ALLOW_COARSE)";
+  }
   if (e != hipSuccess) {
     delete c;
-    return hip_fail(e, "mailbox allocation", __FILE__, __LINE__);
+    (void)hipGetLastError();
+    set_error("pclmi_comm: neither uncached nor fine-grained device memory is available for the mailbox (%s)",
+              hipGetErrorString(e));
+    return PCLMI_ERR_HIP;
   }
   c->seq = (unsigned int *)(c->box + kCommBoxWords);
   if ((e = hipMemset(c->box, 0, bytes)) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess) {
@@ -151,6 +185,7 @@ int pclmi_comm_create_shm(int rank, int world, const char *name, pclmi_comm **ou
   struct Shm {
     std::atomic<uint32_t> ready[kCommMaxRanks];
     std::atomic<uint32_t> done;
+    std::atomic<int64_t> creator_pid;  // rank 0's pid: a segment whose creator is gone is a crashed job's
     unsigned char handles[kCommMaxRanks][PCLMI_COMM_HANDLE_BYTES];
   };
   char path[256];
@@ -161,35 +196,79 @@ int pclmi_comm_create_shm(int rank, int world, const char *name, pclmi_comm **ou
     return (int)PCLMI_ERR_HIP;
   };
   const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(120);
-  int fd = -1;
-  if (rank == 0) {
-    shm_unlink(path);  // a stale segment of a crashed job
-    fd = shm_open(path, O_CREAT | O_EXCL | O_RDWR, 0600);
-    if (fd < 0 || ftruncate(fd, sizeof(Shm)) != 0) return fail("cannot create the segment");
-  } else {
-    for (;;) {
-      fd = shm_open(path, O_RDWR, 0600);
-      struct stat st;
-      if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= sizeof(Shm)) break;
-      if (fd >= 0) close(fd);
-      fd = -1;
-      if (std::chrono::steady_clock::now() > deadline) return fail("rank 0 never created the segment");
-      std::this_thread::sleep_for(std::chrono::milliseconds(2));
-    }
-  }
-  Shm *sh = (Shm *)mmap(nullptr, sizeof(Shm), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-  close(fd);
-  if (sh == MAP_FAILED) return fail("mmap failed");
-  std::memcpy(sh->handles[rank], mine, PCLMI_COMM_HANDLE_BYTES);
-  sh->ready[rank].store(1u, std::memory_order_release);
-  for (int p = 0; p < world; ++p)
-    while (sh->ready[p].load(std::memory_order_acquire) != 1u) {
-      if (std::chrono::steady_clock::now() > deadline) {
-        munmap(sh, sizeof(Shm));
-        return fail("a peer never arrived");
+  Shm *sh = nullptr;
+  for (;;) {  // (a non-zero rank starts over when the object it mapped turns out to be a stale one)
+    int fd = -1;
+    if (rank == 0) {
+      shm_unlink(path);  // a stale segment of a crashed job
+      fd = shm_open(path, O_CREAT | O_EXCL | O_RDWR, 0600);
+      if (fd < 0) return fail("cannot create the segment");
+      if (ftruncate(fd, sizeof(Shm)) != 0) {
+        close(fd);
+        shm_unlink(path);
+        return fail("cannot size the segment");
       }
-      std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    } else {
+      for (;;) {
+        fd = shm_open(path, O_RDWR, 0600);
+        struct stat st;
+        if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= sizeof(Shm)) break;
+        if (fd >= 0) close(fd);
+        fd = -1;
+        if (std::chrono::steady_clock::now() > deadline) return fail("rank 0 never created the segment");
+        std::this_thread::sleep_for(std::chrono::milliseconds(2));
+      }
     }
+    struct stat st0;
+    const bool have_ino = fstat(fd, &st0) == 0;
+    sh = (Shm *)mmap(nullptr, sizeof(Shm), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (sh == MAP_FAILED) {
+      if (rank == 0) shm_unlink(path);
+      return fail("mmap failed");
+    }
+    if (rank == 0) sh->creator_pid.store((int64_t)getpid(), std::memory_order_release);
+    bool stale = false;
+    if (rank != 0) {
+      // wait for the creator's pid, then make sure that process exists: the segment of a crashed job holds ready
+      // flags and IPC handles of dead processes
+      int64_t cp = 0;
+      while ((cp = sh->creator_pid.load(std::memory_order_acquire)) == 0 && !stale) {
+        if (std::chrono::steady_clock::now() > deadline) {
+          munmap(sh, sizeof(Shm));
+          return fail("rank 0 never published its pid");
+        }
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+      }
+      if (kill((pid_t)cp, 0) != 0 && errno == ESRCH) stale = true;
+    }
+    if (!stale) {
+      std::memcpy(sh->handles[rank], mine, PCLMI_COMM_HANDLE_BYTES);
+      sh->ready[rank].store(1u, std::memory_order_release);
+      for (int p = 0; p < world && !stale; ++p)
+        while (sh->ready[p].load(std::memory_order_acquire) != 1u) {
+          if (std::chrono::steady_clock::now() > deadline) {
+            munmap(sh, sizeof(Shm));
+            if (rank == 0) shm_unlink(path);
+            return fail("a peer never arrived");
+          }
+          std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        }
+      if (rank != 0 && have_ino) {
+        // the name must still lead to the object that was mapped (rank 0 replaces a stale one when it arrives); once the
+        // rendezvous has completed the name may already be gone (the last rank unlinks it): that is fine
+        const int fd2 = shm_open(path, O_RDWR, 0600);
+        struct stat st1;
+        if (fd2 >= 0 && fstat(fd2, &st1) == 0 && st1.st_ino != st0.st_ino) stale = true;
+        if (fd2 >= 0) close(fd2);
+      }
+    }
+    if (!stale) break;
+    munmap(sh, sizeof(Shm));
+    sh = nullptr;
+    if (std::chrono::steady_clock::now() > deadline) return fail("only a stale segment of an earlier job was found");
+    std::this_thread::sleep_for(std::chrono::milliseconds(5));
+  }
   int rc = pclmi_comm_connect(c, &sh->handles[0][0]);
   if (sh->done.fetch_add(1u) + 1u == (uint32_t)world) shm_unlink(path);
   munmap(sh, sizeof(Shm));
@@ -216,9 +295,11 @@ int pclmi_comm_allreduce_f64(pclmi_comm *c, double *d_buf, int count, void *stre
               kCommMaxCount);
   PCLMI_CHECK(c->connected, PCLMI_ERR_INVALID, "communicator is not connected (pclmi_comm_connect)");
   if (c->world == 1) return PCLMI_OK;
+  PCLMI_CHECK(!c->dead, PCLMI_ERR_COMM,
+              "an earlier exchange of this communicator timed out: destroy it and create a new one on every rank");
   PCLMI_HIP(hipSetDevice(c->device));
   // the status word lives behind the sequence counter in the (zero-initialised) mailbox block
-  int *status = (int *)(c->seq + 4);
+  int *status = (int *)(c->seq + kCtrlStatus);
   hipLaunchKernelGGL(comm_allreduce_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, c->view(), d_buf, count, status);
   PCLMI_HIP(hipGetLastError());
   return PCLMI_OK;
@@ -228,10 +309,13 @@ int pclmi_comm_status(pclmi_comm *c) {
   PCLMI_CHECK(c, PCLMI_ERR_INVALID, "NULL argument");
   PCLMI_HIP(hipSetDevice(c->device));
   PCLMI_HIP(hipDeviceSynchronize());
-  int st = 0;
-  PCLMI_HIP(hipMemcpy(&st, (int *)(c->seq + 4), sizeof(int), hipMemcpyDeviceToHost));
-  PCLMI_CHECK(st == 0, PCLMI_ERR_COMM, "a peer's data did not arrive within %.1f s (rank %d of %d)", c->timeout_s,
-              c->rank, c->world);
+  unsigned int st[kCtrlDead + 1] = {0};
+  PCLMI_HIP(hipMemcpy(st, c->seq, sizeof(st), hipMemcpyDeviceToHost));
+  if (st[kCtrlStatus] != 0u || st[kCtrlDead] != 0u) c->dead = true;
+  PCLMI_CHECK(!c->dead, PCLMI_ERR_COMM,
+              "a peer's data did not arrive within %.1f s (rank %d of %d, %s mailbox): the communicator is dead - "
+              "destroy it and create a new one on every rank",
+              c->timeout_s, c->rank, c->world, c->memory);
   return PCLMI_OK;
 }
 

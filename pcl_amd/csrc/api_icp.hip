@@ -298,11 +298,11 @@ int pclmi_icp_begin_sharded(const pclmi_tree *target, const float *src, size_t n
   if (!(lo[0] <= hi[0])) lo[0] = lo[1] = lo[2] = hi[0] = hi[1] = hi[2] = 0.f;
   if ((rc = c->pts.alloc(n_src)) || (rc = c->order.alloc(n_src)) || (rc = c->inv.alloc(n_src)) ||
       (rc = c->nn.alloc(n_src)) || (rc = c->nn_slot.alloc(n_src)) || (rc = c->dist.alloc(n_src)) ||
-      (rc = c->partials.alloc((size_t)std::max(icp_step_blocks(n_src), pair_reduce_blocks(n_src)) * PCLMI_ICP_NSUMS_PLANE)) ||
-      (rc = c->sums.alloc(PCLMI_ICP_NSUMS_PLANE)))
+      (rc = c->partials.alloc((size_t)std::max(icp_step_blocks(n_src), pair_reduce_blocks(n_src)) * kIcpMaxSums)) ||
+      (rc = c->sums.alloc(kIcpMaxSums)))
     return fail(rc);
   c->groups = icp_step_groups(n_src);
-  if ((rc = c->gpart.alloc((size_t)c->groups * PCLMI_ICP_NSUMS_PLANE)) || (rc = c->tickets.alloc(c->groups + 1))) return fail(rc);
+  if ((rc = c->gpart.alloc((size_t)c->groups * kIcpMaxSums)) || (rc = c->tickets.alloc(c->groups + 1))) return fail(rc);
   if (hipMemsetAsync(c->tickets.p, 0, (c->groups + 1) * sizeof(unsigned int), c->stream) != hipSuccess)
     return fail(hip_fail(hipGetLastError(), "memset", __FILE__, __LINE__));
   {
@@ -379,7 +379,7 @@ int pclmi_icp_begin_sharded(const pclmi_tree *target, const float *src, size_t n
 // fused: the launch's last workgroup also exchanges the sums with the other ranks (when a communicator is attached)
 // and runs the solve; otherwise it only leaves the rank's sums in d_sums
 static int icp_step_enqueue(pclmi_icp_ctx *c, double max_correspondence_distance, double *d_sums, void *stream,
-                            bool fused) {
+                            bool fused, unsigned char *d_keep_slot = nullptr) {
   PCLMI_CHECK(c && d_sums, PCLMI_ERR_INVALID, "NULL argument");
   PCLMI_HIP(hipSetDevice(c->tree->device));
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
@@ -392,12 +392,12 @@ static int icp_step_enqueue(pclmi_icp_ctx *c, double max_correspondence_distance
   tail.ticket = c->tickets.p + c->groups;
   tail.sums_out = d_sums;
   tail.st = c->dev_mode ? c->state.p : nullptr;
-  tail.solve = fused ? 1 : 0;
+  tail.solve = (fused && !d_keep_slot) ? 1 : 0;  // the RANSAC loop's step: the refit launch solves
   tail.ngroups = (int)c->groups;
   if (fused && c->comm) tail.comm = comm_view(c->comm);
   launch_icp_step(c->tree, c->pts.p, c->n, c->pending, make_xf(c->T), thr2, c->nn.p, c->nn_slot.p, c->dist.p, c->origin,
                   c->partials.p, s, c->dev_mode ? c->state.p : nullptr, c->stepped, tail,
-                  c->plane ? c->tn_slot.p : nullptr, c->has_skip ? c->src_skip.p : nullptr);
+                  c->plane ? c->tn_slot.p : nullptr, c->has_skip ? c->src_skip.p : nullptr, d_keep_slot);
   c->pending = false;
   c->stepped = true;
   PCLMI_HIP(hipGetLastError());
@@ -552,7 +552,7 @@ int pclmi_icp_state(pclmi_icp_ctx *c, float final_T[16], pclmi_icp_stats *stats)
     stats->iterations = h.iterations;
     stats->converged = h.converged;
     stats->last_correspondences = h.last_pairs;
-    stats->last_inliers = h.last_pairs;
+    stats->last_inliers = h.last_inliers;
     stats->fitness_delta = h.fit;
     stats->transform_delta = h.tdelta;
     std::memcpy(stats->last_transform, h.T, sizeof(h.T));
@@ -837,6 +837,119 @@ int ransac_icp(pclmi_icp_ctx *c, RansacScratch &rs, const pclmi_icp_params *p, i
 
 namespace {
 
+// ---- RANSAC rejection inside the device-resident loop (icp_kernels.hip "RANSAC loop") ---------------------------
+struct RansacLoopBufs {
+  DevBuf<RansacLoopState> rl;
+  DevBuf<RansacRng> rng0, rng;
+  DevBuf<unsigned long long> shuf, keep_bits;
+  DevBuf<unsigned int> sb_cnt, sb_prefix;
+  DevBuf<RansacTrial> trials;
+  DevBuf<unsigned char> keep_slot;
+  DevBuf<double> sums2;  // the refit launch's sums
+  RansacLoopArgs a;
+  int init(pclmi_icp_ctx *c, const pclmi_icp_params *p) {
+    hipStream_t s = c->stream;
+    const size_t n_rows = c->n_full;
+    const int nsb = (int)((n_rows + 1023) / 1024);
+    RC(rl.alloc(1));
+    RC(rng0.alloc(1));
+    RC(rng.alloc(1));
+    RC(shuf.alloc(n_rows));
+    RC(keep_bits.alloc((size_t)nsb * 16));
+    RC(sb_cnt.alloc(nsb));
+    RC(sb_prefix.alloc(nsb));
+    RC(trials.alloc(kRansacBatch));
+    RC(keep_slot.alloc(c->n));
+    RC(sums2.alloc(kIcpMaxSums));
+    PCLMI_HIP(hipMemsetAsync(rl.p, 0, sizeof(RansacLoopState), s));
+    PCLMI_HIP(hipMemsetAsync(shuf.p, 0, n_rows * sizeof(unsigned long long), s));  // tag 0: no entry is current
+    launch_ransac_seed(rng0.p, 12345u, s);  // boost::mt19937 seed 12345 (sac_model.h:95)
+    a.rl = rl.p;
+    a.st = c->state.p;
+    a.sums = c->sums.p;
+    a.est = c->plane ? 1 : 0;
+    a.n = (int)c->n;
+    a.n_rows = (int)n_rows;
+    a.min_corr = p->min_correspondences;
+    a.max_trials = p->ransac_iterations;
+    a.inlier_thr2 = p->ransac_outlier_threshold * p->ransac_outlier_threshold;
+    a.rng0 = rng0.p;
+    a.rng = rng.p;
+    a.shuf = shuf.p;
+    a.inv = c->inv.p;
+    a.pts = c->pts.p;
+    a.nn_slot = c->nn_slot.p;
+    a.rows = (const float4 *)c->tree->d_slot;
+    a.keep_slot = keep_slot.p;
+    a.keep_bits = keep_bits.p;
+    a.sb_cnt = sb_cnt.p;
+    a.sb_prefix = sb_prefix.p;
+    a.nsb = nsb;
+    a.trials = trials.p;
+    a.comm = CommView();
+    return PCLMI_OK;
+  }
+};
+
+// one iteration of the RANSAC loop, enqueued without waiting: step, first batch of trials, refit + solve
+int ransac_loop_enqueue(pclmi_icp_ctx *c, RansacLoopBufs &rb, const pclmi_icp_params *p, int first) {
+  hipStream_t s = c->stream;
+  if (first) {
+    RC(icp_step_enqueue(c, p->max_correspondence_distance, c->sums.p, nullptr, true, rb.keep_slot.p));
+    launch_ransac_loop_batch(rb.a, 1, 4, s);  // a converged iteration needs ONE trial (99.9 % inliers: k < 1)
+  }
+  IcpTail tail;
+  tail.gpart = c->gpart.p;
+  tail.gticket = c->tickets.p;
+  tail.ticket = c->tickets.p + c->groups;
+  tail.sums_out = rb.sums2.p;
+  tail.st = c->state.p;
+  tail.solve = 1;
+  tail.ngroups = (int)c->groups;
+  tail.carry = c->sums.p;
+  if (c->comm) tail.comm = comm_view(c->comm);
+  launch_ransac_loop_refit(rb.a, c->tree, first, c->origin, c->partials.p, tail, c->plane ? c->tn_slot.p : nullptr,
+                           c->has_skip ? c->src_skip.p : nullptr, nullptr, s);
+  PCLMI_HIP(hipGetLastError());
+  return PCLMI_OK;
+}
+
+// the whole align with the rejection step on; the host only reads the state between chunks of iterations and feeds
+// further batches of trials to an iteration whose first batch did not satisfy the stopping rule
+int ransac_loop_align(pclmi_icp_ctx *c, const pclmi_icp_params *p, float final_T[16], pclmi_icp_stats *st) {
+  RansacLoopBufs rb;
+  RC(rb.init(c, p));
+  RC(pclmi_icp_set_criteria(c, p));
+  c->dev_mode = true;
+  hipStream_t s = c->stream;
+  int chunk = 1;
+  for (;;) {
+    const int left = std::max(1, p->max_iterations - st->iterations);
+    const int now = std::min(chunk, left);
+    for (int i = 0; i < now; ++i) RC(ransac_loop_enqueue(c, rb, p, 1));
+    IcpDevState h;
+    PCLMI_HIP(hipMemcpyAsync(&h, c->state.p, sizeof(h), hipMemcpyDeviceToHost, s));
+    PCLMI_HIP(hipStreamSynchronize(s));
+    const bool stalled = h.hold != 0;
+    while (h.hold && !h.done) {  // further batches for the iteration that waits (ransac.hpp:71-121)
+      launch_ransac_loop_batch(rb.a, 0, kRansacBatch, s);
+      RansacLoopState hr;
+      PCLMI_HIP(hipMemcpyAsync(&hr, rb.rl.p, sizeof(hr), hipMemcpyDeviceToHost, s));
+      PCLMI_HIP(hipStreamSynchronize(s));
+      if (!hr.settled) continue;
+      RC(ransac_loop_enqueue(c, rb, p, 0));
+      PCLMI_HIP(hipMemcpyAsync(&h, c->state.p, sizeof(h), hipMemcpyDeviceToHost, s));
+      PCLMI_HIP(hipStreamSynchronize(s));
+      PCLMI_CHECK(h.hold == 0 || h.done, PCLMI_ERR_HIP, "internal: the RANSAC loop's refit did not run");
+    }
+    const int rc = pclmi_icp_state(c, final_T, st);
+    if (rc) return rc;
+    if (h.done) break;
+    chunk = stalled ? 1 : std::min(8, chunk * 2);
+  }
+  return PCLMI_OK;
+}
+
 struct PlaneArgs {
   const float *src_normals;
   size_t sn_stride;
@@ -972,6 +1085,17 @@ int align_core(const pclmi_icp_params *p, const pclmi_tree *target, const float 
     int rc2 = pclmi_icp_end(c, aligned);
     return rc ? rc : rc2;
   }
+  if (!rc && !obs.fn && world == 1) {
+    // the reference's default: RANSAC rejection on.  Device-resident as well (icp_kernels.hip "RANSAC loop")
+    pclmi_icp_stats st;
+    std::memset(&st, 0, sizeof(st));
+    set_identity(st.last_transform);
+    rc = ransac_loop_align(c, p, final_T, &st);
+    if (stats) *stats = st;
+    int rc2 = pclmi_icp_end(c, aligned);
+    return rc ? rc : rc2;
+  }
+  // with an observer the pairs of every iteration go to the host anyway: the host-driven loop
   float T[16], Tprev[16];
   set_identity(T);
   RansacScratch rs;

@@ -131,12 +131,21 @@ constexpr int NS = PCLMI_ICP_NSUMS;  // 24
 constexpr int NSP = PCLMI_ICP_NSUMS_PLANE;  // 32: the point-to-plane loop (layout: pclmi.h)
 constexpr int ICP_WPB = 4;
 // EST: 0 = TransformationEstimationSVD, 1 = TransformationEstimationPointToPlaneLLS
-template <int EST>
+// RS: the step of the RANSAC loop - one more group of eight sums: the moments of the PAIRED source points about the
+// origin, from which sample_dist_thresh_ of the iteration's SampleConsensusModelRegistration is computed
+// (sac_model_registration.h:257-279) without another pass over the points
+template <int EST, bool RS = false>
 struct SumsOf {
-  static constexpr int n = EST ? NSP : NS;
+  static constexpr int n = (EST ? NSP : NS) + (RS ? 8 : 0);
   static constexpr int pairs = EST ? 27 : 0;     // pairs under the distance threshold
+  static constexpr int dsum = EST ? 28 : 16;     // sum min(d2, thr2)
   static constexpr int fit_num = EST ? 29 : 17;  // sum (d_now - d_prev)
   static constexpr int points = EST ? 30 : 18;   // points searched
+  // RS only: sum s (3 values; EST = 0 has them anyway) and sum s s' (xx, xy, xz, yy, yz, zz) over the pairs
+  static constexpr int mom1 = EST ? 31 : 1;
+  static constexpr int mom2 = EST ? 34 : 24;
+  // the sums a refit launch of the RANSAC loop takes over from the step (IcpTail::carry): [carry0, carry1)
+  static constexpr int carry0 = EST ? 28 : 16, carry1 = EST ? 32 : 24;
 };
 
 // One lane turns the (all-reduced) sums into the next transform and evaluates the convergence criteria
@@ -169,6 +178,7 @@ __device__ __forceinline__ void icp_solve_body(const double *__restrict__ sums, 
   const double *h = sums;
   const long long cnt = llround(h[SumsOf<EST>::pairs]);
   st->last_pairs = (int)cnt;
+  st->last_inliers = (int)cnt;
   if (cnt < (long long)in->min_corr) {  // icp.hpp:103-108
     st->status = PCLMI_ERR_NOT_ENOUGH;
     st->done = 1;
@@ -241,10 +251,10 @@ __device__ __forceinline__ double tail_column_sum(const double *col_base, int cn
 // workgroup happens to be last), exchanges them with the other ranks when a communicator is attached (comm_dev.hpp),
 // writes sums_out and, when asked, runs the solve.  Nobody waits for anybody inside the GPU: a workgroup that is not
 // last simply ends.  Returns to the caller only in the last workgroup's first wave... never: everything happens here.
-template <int EST>
+template <int EST, bool RS = false>
 __device__ __forceinline__ void icp_step_tail(const IcpTail &tail, double *__restrict__ partials,
-                                              double (*lds)[SumsOf<EST>::n]) {
-  constexpr int NS = SumsOf<EST>::n;  // shadows the SVD loop's count
+                                              double (*lds)[SumsOf<EST, RS>::n]) {
+  constexpr int NS = SumsOf<EST, RS>::n;  // shadows the SVD loop's count
   __shared__ int s_last;
   __shared__ double fin[NS];
   __shared__ double svd_work[42];
@@ -268,9 +278,11 @@ __device__ __forceinline__ void icp_step_tail(const IcpTail &tail, double *__res
   }
   __syncthreads();
   if (!s_last) return;
-  const int col = tid >> 3, r = tid & 7;
-  const bool colth = tid < NS * 8;
-  {
+  const int r = tid & 7;
+#pragma unroll
+  for (int c0 = 0; c0 < NS; c0 += 32) {  // 32 columns per round (8 lanes each): one round up to 32 sums
+    const int col = c0 + (tid >> 3);
+    const bool colth = col < NS;
     const double s = tail_column_sum(partials + (size_t)(colth ? col : 0) * nblk + (size_t)g * ICP_GROUP, gsize, r, colth);
     if (colth && r == 0) st_agent(&tail.gpart[(size_t)col * tail.ngroups + g], s);
   }
@@ -284,7 +296,10 @@ __device__ __forceinline__ void icp_step_tail(const IcpTail &tail, double *__res
   __syncthreads();
   if (!s_last) return;
   const unsigned long long tk1 = (unsigned long long)wall_clock64();
-  {
+#pragma unroll
+  for (int c0 = 0; c0 < NS; c0 += 32) {
+    const int col = c0 + (tid >> 3);
+    const bool colth = col < NS;
     const double s = tail_column_sum(tail.gpart + (size_t)(colth ? col : 0) * tail.ngroups, tail.ngroups, r, colth);
     if (colth && r == 0) fin[col] = s;
   }
@@ -297,6 +312,12 @@ __device__ __forceinline__ void icp_step_tail(const IcpTail &tail, double *__res
     const unsigned int seq = *tail.comm.seq + 1u;
     ok = comm_allreduce_wave(tail.comm, v, NS, lane, seq);
     if (lane == 0) *tail.comm.seq = seq;
+  }
+  // refit launch of the RANSAC loop: what is summed over ALL points (and was exchanged by the step) is the step's
+  long long step_pairs = -1;
+  if (tail.carry) {
+    if (lane >= SumsOf<EST>::carry0 && lane < SumsOf<EST>::carry1) v = tail.carry[lane];
+    step_pairs = llround(tail.carry[SumsOf<EST>::pairs]);
   }
   if (lane < NS) {
     tail.sums_out[lane] = v;  // read by later launches / the host only: a plain store
@@ -314,6 +335,11 @@ __device__ __forceinline__ void icp_step_tail(const IcpTail &tail, double *__res
         st->done = 1;
       } else if (tail.solve) {
         icp_solve_body<EST>(fin, st, svd_work, &sin);
+        st->last_inliers = st->last_pairs;
+        if (step_pairs >= 0) {
+          st->last_pairs = (int)step_pairs;
+          st->hold = 0;  // the iteration the host was asked to finish is complete
+        }
       }
       st->ticks[3] = (unsigned long long)wall_clock64();
     }
@@ -328,7 +354,9 @@ __device__ __forceinline__ void icp_step_tail(const IcpTail &tail, double *__res
 // instead of the moments of the SVD estimator every pair adds its row of the linearised point-to-plane system to the
 // 21 + 6 sums of the 6x6 normal equations; tn_slot holds the target normals in bucket-slot order (next to the point a
 // lane has just found), src_skip (nullable) flags source points whose own normal is not finite (:158-174 skips them).
-template <bool LANE, int EST>
+// RS: the step of the RANSAC loop (pclmi_icp_align with ransac_iterations > 0): also leaves keep_slot[slot] = "this
+// point has a pair" for the passes of the rejection step and adds the paired source points' second moments.
+template <bool LANE, int EST, bool RS>
 __global__ __launch_bounds__(64 * ICP_WPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void icp_step_kernel(TreeView t, float4 *__restrict__ pts, int n,
                                                                  int apply, Xf T, float thr2f, double thr2,
                                                                  int *__restrict__ nn_idx, int *__restrict__ nn_slot,
@@ -337,12 +365,13 @@ __global__ __launch_bounds__(64 * ICP_WPB) __attribute__((amdgpu_waves_per_eu(8,
                                                                  const IcpDevState *__restrict__ st, int levels,
                                                                  int have_prev, IcpTail tail,
                                                                  const float4 *__restrict__ tn_slot,
-                                                                 const unsigned char *__restrict__ src_skip) {
+                                                                 const unsigned char *__restrict__ src_skip,
+                                                                 unsigned char *__restrict__ keep_slot) {
   static_assert(LANE || !EST, "the point-to-plane loop reads the target normals by bucket slot");
   extern __shared__ float far_lds[];
-  __shared__ double lds[ICP_WPB][SumsOf<EST>::n];
+  __shared__ double lds[ICP_WPB][SumsOf<EST, RS>::n];
   if (st) {  // device-resident loop: the pending transform and the stop flag live in device memory
-    if (st->done) return;
+    if (st->done || (RS && st->hold)) return;
     apply = st->apply;
 #pragma unroll
     for (int j = 0; j < 12; ++j) T.m[j] = st->T[j];
@@ -419,6 +448,7 @@ __global__ __launch_bounds__(64 * ICP_WPB) __attribute__((amdgpu_waves_per_eu(8,
       const float d = searchable ? __uint_as_float((unsigned int)(best >> 32)) : __builtin_nanf("");
       nn_idx[slot] = idx;
       nn_slot[slot] = searchable ? bslot : -1;
+      if (RS) keep_slot[slot] = (searchable && (double)d < thr2) ? 1 : 0;
       if (searchable) {
         dc = fminf(d, thr2f);  // icp.hpp:101
         prev = dist[slot];
@@ -465,13 +495,18 @@ __global__ __launch_bounds__(64 * ICP_WPB) __attribute__((amdgpu_waves_per_eu(8,
       double v[8] = {nx * ny, nx * nz, ny * ny, ny * nz, nz * nz, a * dd, b * dd, c * dd};
       wave_reduce_to_row(v, contrib, &lds[wib][16], lane);
     }
+    const double sx = (double)p.x - ox, sy = (double)p.y - oy, sz = (double)p.z - oz;  // RS only
     {
       double v[8] = {contrib ? nx * dd : 0.0, contrib ? ny * dd : 0.0, contrib ? nz * dd : 0.0, paired ? 1.0 : 0.0,
-                     (double)dc,              (double)dc - (double)prev,  1.0,                      0.0};
+                     (double)dc,              (double)dc - (double)prev,  1.0,                      (RS && paired) ? sx : 0.0};
       wave_reduce_to_row(v, counted, &lds[wib][24], lane);
     }
+    if constexpr (RS) {
+      double v[8] = {sy, sz, sx * sx, sx * sy, sx * sz, sy * sy, sy * sz, sz * sz};
+      wave_reduce_to_row(v, paired, &lds[wib][32], lane);
+    }
     __syncthreads();
-    icp_step_tail<1>(tail, partials, lds);
+    icp_step_tail<1, RS>(tail, partials, lds);
   } else {
   // fp64 moments, reduced in three groups of eight so that at most 16 accumulator registers are live at a
   // time (the register budget is 64 VGPRs = 8 waves per SIMD: the search is latency-bound)
@@ -490,8 +525,12 @@ __global__ __launch_bounds__(64 * ICP_WPB) __attribute__((amdgpu_waves_per_eu(8,
     double v[8] = {(double)dc, (double)dc - (double)prev, one_c, ox, oy, oz, 0.0, 0.0};
     wave_reduce_to_row(v, counted, &lds[wib][16], lane);
   }
+  if constexpr (RS) {
+    double v[8] = {sx * sx, sx * sy, sx * sz, sy * sy, sy * sz, sz * sz, 0.0, 0.0};
+    wave_reduce_to_row(v, paired, &lds[wib][24], lane);
+  }
   __syncthreads();
-  icp_step_tail<0>(tail, partials, lds);
+  icp_step_tail<0, RS>(tail, partials, lds);
   }
 }
 
@@ -704,8 +743,7 @@ __global__ __launch_bounds__(256) void count_within_kernel(const float4 *__restr
 // sample_dist_thresh_ = (mean of the square roots of the eigenvalues of the source points' covariance)^2
 // (computeSampleDistanceThreshold, sac_model_registration.h:257-279; cyclic Jacobi stands in for pcl::eigen33).
 // m: the sums of moment_reduce_kernel (second moments 0..5, first moments 6..8, count 9).
-__global__ void ransac_sample_threshold_kernel(const double *__restrict__ m, double *__restrict__ out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ __forceinline__ double sample_threshold_from_moments(const double *m) {
   const double inv_n = 1.0 / m[9];
   double a[9];
   for (int i = 0; i < 9; ++i) a[i] = m[i] * inv_n;
@@ -739,7 +777,12 @@ __global__ void ransac_sample_threshold_kernel(const double *__restrict__ m, dou
   double sthr = 0.0;
   for (int i = 0; i < 3; ++i) sthr += sqrt(ev[i] > 0 ? ev[i] : 0.0);
   sthr /= 3.0;
-  out[0] = sthr * sthr;
+  return sthr * sthr;
+}
+
+__global__ void ransac_sample_threshold_kernel(const double *__restrict__ m, double *__restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  out[0] = sample_threshold_from_moments(m);
 }
 
 __global__ void ransac_seed_kernel(RansacRng *rng, unsigned int seed) {
@@ -750,7 +793,13 @@ __global__ void ransac_seed_kernel(RansacRng *rng, unsigned int seed) {
     x = 1812433253u * (x ^ (x >> 30)) + (unsigned int)i;
     rng->mt[i] = x;
   }
-  rng->idx = 624;
+  // the first twist is done here, once, instead of at the head of every call's first draw
+  unsigned int *mt = rng->mt;
+  for (int i = 0; i < 624; ++i) {
+    const unsigned int y = (mt[i] & 0x80000000u) | (mt[(i + 1) % 624] & 0x7fffffffu);
+    mt[i] = mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+  }
+  rng->idx = 0;
 }
 
 __device__ __forceinline__ unsigned int mt_next(unsigned int *mt, int &idx) {  // one lane; mt in LDS
@@ -1023,6 +1072,629 @@ __global__ __launch_bounds__(256) void fitness_kernel(const float *__restrict__ 
   }
 }
 
+// ---- RANSAC loop: the rejection step of icp.hpp:113-150 without the host -----------------------------------------
+// One ICP iteration with the reference's default ransac_iterations_ = 1000 is four launches, none of which the host
+// waits for: the step (icp_step_kernel<.., RS = true>: pairs, keep mask, the step's sums incl. the source moments),
+// ransac_draw_loop_kernel (the sampling stream + the three-point models of one batch), ransac_count_loop_kernel (the
+// inliers of every model of the batch in one pass; its last workgroup applies the reference's stopping rule,
+// ransac.hpp:71-121) and ransac_refit_kernel (selectWithinDistance with the best model fused with the refit sums of
+// icp.hpp:171, then the step's tail: reduction, exchange, solve, convergence criteria).  When the first batch does
+// not satisfy the stopping rule (few inliers: the first iterations of an align), the count kernel sets st->hold, every
+// later launch of the speculatively enqueued chunk is a no-op, and the host enqueues further batches (first = 0).
+// Positions of the pair list: the reference's list is in ORIGINAL source order; position -> row is the identity when
+// every row has a pair, otherwise a rank / select over the pair bit mask by row (ransac_keep_words_kernel: one word
+// per 64 rows, one count per 1024) - no compaction, no gathers over the whole list.
+// shuffled_indices_ (sac_model.h) is reset for every iteration's model: entries carry the iteration's tag, an entry
+// with another tag reads as its own position; what a batch changes lives in registers until its end.
+constexpr int kSbRows = 1024;  // rows per count of the select structure
+
+// the comm failed under a kernel of the RANSAC loop: the align ends with PCLMI_ERR_COMM
+__device__ __forceinline__ void ransac_comm_failed(const RansacLoopArgs &a) {
+  a.st->status = PCLMI_ERR_COMM;
+  a.st->done = 1;
+}
+
+// local pair mask by row (rows of other ranks: 0), pushed to every peer's bulk window when sharded; nobody waits here
+__global__ __launch_bounds__(kSbRows) void ransac_keep_words_kernel(RansacLoopArgs a) {
+  if (a.st->done || a.st->hold) return;
+  if (llround(a.sums[a.est ? 27 : 0]) == (long long)a.n_rows) return;  // every row has a pair
+  const int row = blockIdx.x * kSbRows + threadIdx.x;
+  bool k = false;
+  if (row < a.n_rows) {
+    const int sl = a.inv[row];
+    k = sl >= 0 && a.keep_slot[sl] != 0;
+  }
+  const unsigned long long w = __ballot(k);
+  if ((threadIdx.x & 63) == 0) {
+    a.keep_bits[row >> 6] = w;  // nsb * 16 words are allocated
+    if (a.comm.world > 1) {
+      const CommView &c = a.comm;
+      const unsigned int bseq = c.seq[kCtrlBulkSeq] + 1u;
+      const unsigned long long tag = (unsigned long long)bseq << 32;
+      const size_t wi = (size_t)(row >> 6);
+      for (int p = 0; p < c.world; ++p) {
+        if (p == c.rank) continue;
+        unsigned long long *dst = c.bulk[p] + ((size_t)((bseq & 1u) * c.world + c.rank) * c.bulk_cap + 2 * wi);
+        __hip_atomic_store((g_u64p)dst, tag | (unsigned int)w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store((g_u64p)(dst + 1), tag | (unsigned int)(w >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
+}
+
+// the peers' words OR-ed in (sharded), then the pair count of every 1024 rows.  A SMALL grid on purpose: its waves
+// wait for the peers' pushes, and a grid that fills the GPU would starve a peer that shares it (tests: two ranks on
+// one device); 16 lanes per block of 1024 rows.
+__global__ __launch_bounds__(64) void ransac_keep_count_kernel(RansacLoopArgs a) {
+  __shared__ int s_last;
+  if (a.st->done || a.st->hold) return;
+  if (llround(a.sums[a.est ? 27 : 0]) == (long long)a.n_rows) return;
+  const CommView &c = a.comm;
+  const int lane = threadIdx.x;
+  const unsigned int bseq = c.world > 1 ? c.seq[kCtrlBulkSeq] + 1u : 0u;
+  bool ok = c.world > 1 ? !comm_is_dead(c) : true;
+  for (int sb = blockIdx.x * 4 + (lane >> 4); sb - (lane >> 4) < a.nsb; sb += gridDim.x * 4) {
+    int cnt = 0;
+    if (sb < a.nsb) {
+      const size_t wi = (size_t)sb * (kSbRows / 64) + (lane & 15);
+      unsigned long long w = a.keep_bits[wi];
+      if (c.world > 1 && ok) {  // the local word is pushed already (ransac_keep_words_kernel): only the wait
+        const long long t0 = wall_clock64();
+        for (int p = 0; p < c.world && ok; ++p) {
+          if (p == c.rank) continue;
+          const unsigned long long *src = c.bulk[c.rank] + ((size_t)((bseq & 1u) * c.world + p) * c.bulk_cap + 2 * wi);
+          unsigned int spins = 0;
+          for (;;) {
+            const unsigned long long x = __hip_atomic_load((g_cu64p)src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const unsigned long long y = __hip_atomic_load((g_cu64p)(src + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((x >> 32) == bseq && (y >> 32) == bseq) {
+              w |= ((unsigned long long)(unsigned int)y << 32) | (unsigned int)x;
+              break;
+            }
+            if ((++spins & 63u) == 0u && (unsigned long long)(wall_clock64() - t0) > c.timeout_ticks) {
+              ok = false;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+          }
+        }
+        a.keep_bits[wi] = w;
+      }
+      cnt = __popcll(w);
+    }
+    cnt += __shfl_xor(cnt, 8);
+    cnt += __shfl_xor(cnt, 4);
+    cnt += __shfl_xor(cnt, 2);
+    cnt += __shfl_xor(cnt, 1);
+    if (sb < a.nsb && (lane & 15) == 0) a.sb_cnt[sb] = (unsigned int)cnt;
+  }
+  if (c.world == 1) return;
+  if (__any(!ok)) {
+    if (lane == 0) {
+      comm_mark_dead(c);
+      ransac_comm_failed(a);
+    }
+  }
+  __threadfence();
+  if (lane == 0) {
+    const unsigned int t = __hip_atomic_fetch_add((g_u32p)(c.seq + kCtrlBulkTicket), 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = t == gridDim.x - 1 ? 1 : 0;
+  }
+  __syncthreads();
+  if (s_last && lane == 0) {
+    __hip_atomic_store((g_u32p)(c.seq + kCtrlBulkTicket), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    c.seq[kCtrlBulkSeq] = bseq;
+  }
+}
+
+// what one batch has changed of the shuffle array: up to 256 (position, value) entries spread over the lanes'
+// registers; every operation is wave-uniform (all lanes call with the same arguments)
+struct ShufMap {
+  int pos[4], val[4];
+  int count;
+};
+__device__ __forceinline__ bool map_get(const ShufMap &m, int j, int &v) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const unsigned long long hit = __ballot(m.pos[e] == j);
+    if (hit) {
+      v = __shfl(m.val[e], __ffsll((long long)hit) - 1);
+      return true;
+    }
+  }
+  return false;
+}
+__device__ __forceinline__ void map_put(ShufMap &m, int j, int v, int lane) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const unsigned long long hit = __ballot(m.pos[e] == j);
+    if (hit) {
+      if (m.pos[e] == j) m.val[e] = v;
+      return;
+    }
+  }
+  const int e = m.count >> 6, l = m.count & 63;
+#pragma unroll
+  for (int e2 = 0; e2 < 4; ++e2)
+    if (e2 == e && lane == l) {
+      m.pos[e2] = j;
+      m.val[e2] = v;
+    }
+  ++m.count;
+}
+
+// position in the pair list -> source row: the pos-th set bit of the pair mask
+__device__ __forceinline__ int select_row(const RansacLoopArgs &a, int pos) {
+  int lo = 0, hi = a.nsb - 1;  // last block whose prefix is <= pos
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((int)__hip_atomic_load((g_u32p)&a.sb_prefix[mid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= pos) lo = mid;
+    else hi = mid - 1;
+  }
+  int rem = pos - (int)__hip_atomic_load((g_u32p)&a.sb_prefix[lo], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long *w = a.keep_bits + (size_t)lo * (kSbRows / 64);
+  int wi = 0;
+  unsigned long long bits = 0;
+  for (; wi < kSbRows / 64; ++wi) {
+    bits = w[wi];
+    const int c = __popcll(bits);
+    if (rem < c) break;
+    rem -= c;
+  }
+  if (wi == kSbRows / 64) return -1;  // cannot happen for pos < the pair count
+  for (; rem > 0; --rem) bits &= bits - 1;
+  return lo * kSbRows + wi * 64 + (__ffsll((long long)bits) - 1);
+}
+
+__global__ __launch_bounds__(64) void ransac_draw_loop_kernel(RansacLoopArgs a, int first, int draws) {
+  __shared__ unsigned int mt[624];
+  __shared__ int jpos[kRansacBatch][3], gval[kRansacBatch][3], dpos[kRansacBatch][3];
+  __shared__ float4 six[kRansacBatch][6];
+  __shared__ int trial_of[kRansacBatch];
+  __shared__ double work[kRansacBatch][42];
+  __shared__ double s_sthr;
+  RansacLoopState *rl = a.rl;
+  IcpDevState *st = a.st;
+  const int lane = threadIdx.x;
+  if (st->done) return;
+  if (first ? st->hold != 0 : (st->hold == 0 || rl->settled != 0)) return;
+  const int i_pairs = a.est ? 27 : 0;
+  int cnt;
+  double sthr;
+  const unsigned int tag = first ? rl->tag + 1u : rl->tag;  // read before lane 0 advances it
+  const int run0 = first ? 0 : rl->bad_run, dead0 = first ? 0 : rl->dead;
+  if (first) {
+    const long long c64 = llround(a.sums[i_pairs]);
+    cnt = (int)c64;
+    if (c64 < (long long)a.min_corr) {  // icp.hpp:103-108, before the rejection step
+      if (lane == 0) {
+        st->last_pairs = cnt;
+        st->last_inliers = cnt;
+        st->status = PCLMI_ERR_NOT_ENOUGH;
+        st->done = 1;
+      }
+      return;
+    }
+    if (lane == 0) {
+      const int mom1 = a.est ? 31 : 1, mom2 = a.est ? 34 : 24;
+      double m[10];
+      for (int i = 0; i < 6; ++i) m[i] = a.sums[mom2 + i];
+      for (int i = 0; i < 3; ++i) m[6 + i] = a.sums[mom1 + i];
+      m[9] = a.sums[i_pairs];
+      s_sthr = cnt >= 3 ? sample_threshold_from_moments(m) : 0.0;
+      rl->tag = tag;
+      rl->cnt = cnt;
+      rl->active = cnt >= 3 ? 1 : 0;  // fewer: getSamples clears the selection, computeModel fails (ransac.hpp:72-76)
+      rl->all_kept = cnt == a.n_rows ? 1 : 0;
+      rl->ntrials = 0;
+      rl->bad_run = 0;
+      rl->dead = 0;
+      rl->iterations = 0;
+      rl->best = -INT32_MAX;
+      rl->have = 0;
+      rl->settled = cnt >= 3 ? 0 : 1;
+      rl->batches = 0;
+      rl->skipped = 0u;
+      rl->k = 1.0;
+      rl->sthr = s_sthr;
+    }
+    if (cnt < 3) return;
+    __syncthreads();
+    sthr = s_sthr;
+  } else {
+    cnt = rl->cnt;
+    sthr = rl->sthr;
+  }
+  const bool all_kept = cnt == a.n_rows;
+  const bool fresh = first != 0;
+  if (first && !all_kept) {  // exclusive prefix of the per-1024-row pair counts
+    const int chunk = (a.nsb + 63) / 64;
+    const int b0 = lane * chunk, b1 = min(a.nsb, b0 + chunk);
+    unsigned int sum = 0;
+    for (int i = b0; i < b1; ++i) sum += a.sb_cnt[i];
+    unsigned int incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned int up = __shfl_up(incl, o);
+      if (lane >= o) incl += up;
+    }
+    unsigned int run = incl - sum;
+    for (int i = b0; i < b1; ++i) {
+      const unsigned int c = a.sb_cnt[i];
+      a.sb_prefix[i] = run;
+      run += c;
+    }
+    __threadfence();  // select_row (other lanes of this wave) reads the prefix with agent-scope loads
+  }
+  const RansacRng *rin = first ? a.rng0 : a.rng;
+  for (int i = lane; i < 624; i += 64) mt[i] = rin->mt[i];
+  int idx = rin->idx;
+  __syncthreads();
+  // (1) the generator's numbers of the whole batch: they depend on nothing but the pair count
+  for (int d = 0; d < draws; ++d)
+    for (int i = 0; i < 3; ++i) {
+      const unsigned int r = mt_next(mt, idx) >> 1;  // every lane computes the same (LDS state, same-value stores)
+      if (lane == 0) jpos[d][i] = i + (int)(r % (unsigned int)(cnt - i));
+    }
+  __syncthreads();
+  // (2) the far ends' entries as earlier batches of this iteration left them, all loads in flight together
+  for (int t = lane; t < 3 * draws; t += 64) {
+    const int j = jpos[t / 3][t % 3];
+    int v = j;
+    if (!fresh) {
+      const unsigned long long g = a.shuf[j];
+      if ((unsigned int)(g >> 32) == tag) v = (int)(unsigned int)g;
+    }
+    gval[t / 3][t % 3] = v;
+  }
+  int head[3] = {0, 1, 2};
+  if (!fresh)
+    for (int i = 0; i < 3; ++i) {
+      const unsigned long long g = a.shuf[i];
+      if ((unsigned int)(g >> 32) == tag) head[i] = (int)(unsigned int)g;
+    }
+  __syncthreads();
+  // (3) drawIndexSample (sac_model.h:401-412) replayed: shuf[i] <-> shuf[i + rnd() % (cnt - i)], i = 0, 1, 2
+  ShufMap map;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) map.pos[e] = -1, map.val[e] = 0;
+  map.count = 0;
+  for (int d = 0; d < draws; ++d) {
+    for (int i = 0; i < 3; ++i) {
+      const int j = jpos[d][i];
+      if (j < 3) {
+        const int t = head[i];
+        // j >= i; the compiler keeps head[] in registers with these selects
+        const int hj = j == 0 ? head[0] : (j == 1 ? head[1] : head[2]);
+        head[i] = hj;
+        if (j == 0) head[0] = t;
+        else if (j == 1) head[1] = t;
+        else head[2] = t;
+      } else {
+        int v;
+        if (!map_get(map, j, v)) v = gval[d][i];
+        map_put(map, j, head[i], lane);
+        head[i] = v;
+      }
+    }
+    if (lane == 0) {
+      dpos[d][0] = head[0];
+      dpos[d][1] = head[1];
+      dpos[d][2] = head[2];
+    }
+  }
+  __syncthreads();
+  // (4) the sampled pairs' coordinates, one lookup chain per lane
+  for (int t = lane; t < 3 * draws; t += 64) {
+    const int pos = dpos[t / 3][t % 3];
+    const int row = all_kept ? pos : select_row(a, pos);
+    const int sl = row >= 0 ? a.inv[row] : -1;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f), q = p;
+    if (sl >= 0) {
+      p = a.pts[sl];
+      q = a.rows[a.nn_slot[sl]];
+    }
+    six[t / 3][2 * (t % 3)] = p;
+    six[t / 3][2 * (t % 3) + 1] = q;
+  }
+  __syncthreads();
+  if (a.comm.world > 1) {
+    // sharded: a sampled row belongs to ONE rank, which holds its point as it stands now and its match; the others
+    // contributed zeros above.  Bitwise OR over the ranks, three 64-bit words per (draw, point): exact for any bits.
+    const int nwords = 9 * draws;
+    unsigned int seq = *a.comm.seq;
+    bool ok = true;
+    for (int w0 = 0; w0 < nwords && ok; w0 += kCommMaxCount) {
+      const int w = w0 + lane, cntw = min(kCommMaxCount, nwords - w0);
+      unsigned long long bits = 0ull;
+      const float *f = reinterpret_cast<const float *>(&six[0][0]);  // item t = w / 3: floats 8 t + {0,1,2} and 8 t + {4,5,6}
+      const int t = w / 3, part = w % 3;
+      if (lane < cntw) {
+        const int i0 = part == 0 ? 0 : (part == 1 ? 2 : 5), i1 = part == 0 ? 1 : (part == 1 ? 4 : 6);
+        bits = ((unsigned long long)__float_as_uint(f[8 * t + i1]) << 32) | __float_as_uint(f[8 * t + i0]);
+      }
+      ++seq;
+      ok = comm_allreduce_bits<kCommOrU64>(a.comm, bits, cntw, lane, seq);
+      if (ok && lane < cntw) {
+        const int i0 = part == 0 ? 0 : (part == 1 ? 2 : 5), i1 = part == 0 ? 1 : (part == 1 ? 4 : 6);
+        float *fw = reinterpret_cast<float *>(&six[0][0]);
+        fw[8 * t + i0] = __uint_as_float((unsigned int)bits);
+        fw[8 * t + i1] = __uint_as_float((unsigned int)(bits >> 32));
+      }
+    }
+    if (lane == 0) *a.comm.seq = seq;
+    if (!ok) {
+      if (lane == 0) ransac_comm_failed(a);
+      return;
+    }
+    __syncthreads();
+  }
+  // (5) isSampleGood (sac_model_registration.hpp:47-60); a trial is a good sample, at most 1000 draws apart
+  bool good = false;
+  if (lane < draws) {
+    auto sq = [](const float4 &u, const float4 &v) {
+      const float dx = u.x - v.x, dy = u.y - v.y, dz = u.z - v.z;
+      return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+    };
+    const float4 s0 = six[lane][0], s1 = six[lane][2], s2 = six[lane][4];
+    good = (double)sq(s1, s0) > sthr && (double)sq(s2, s0) > sthr && (double)sq(s2, s1) > sthr;
+  }
+  const unsigned long long gm = __ballot(good);
+  int nt = 0, run = run0, dead = dead0;
+  for (int d = 0; d < draws && !dead; ++d) {
+    if ((gm >> d) & 1ull) {
+      if (lane == 0) trial_of[nt] = d;
+      ++nt;
+      run = 0;
+    } else if (++run >= 1000) {  // max_sample_checks_ (sac_model.h:470)
+      dead = 1;
+    }
+  }
+  __syncthreads();
+  // (6) three-point models (estimateRigidTransformationSVD, sac_model_registration.hpp:257-302), one per lane
+  if (lane < nt) {
+    RansacTrial tr;
+    for (int i = 0; i < 16; ++i) tr.T[i] = (i % 5 == 0) ? 1.f : 0.f;
+    tr.status = 0;
+    tr.count = 0u;
+    tr.pad[0] = tr.pad[1] = 0;
+    const float4 *h6 = six[trial_of[lane]];
+    double sm[PCLMI_ICP_NSUMS];
+    for (int i = 0; i < PCLMI_ICP_NSUMS; ++i) sm[i] = 0.0;
+    const double o[3] = {h6[1].x, h6[1].y, h6[1].z};
+    for (int i = 0; i < 3; ++i) {
+      const double sx = h6[2 * i].x - o[0], sy = h6[2 * i].y - o[1], sz = h6[2 * i].z - o[2];
+      const double tx = h6[2 * i + 1].x - o[0], ty = h6[2 * i + 1].y - o[1], tz = h6[2 * i + 1].z - o[2];
+      sm[0] += 1;
+      sm[1] += sx; sm[2] += sy; sm[3] += sz;
+      sm[4] += tx; sm[5] += ty; sm[6] += tz;
+      sm[7] += sx * tx; sm[8] += sx * ty; sm[9] += sx * tz;
+      sm[10] += sy * tx; sm[11] += sy * ty; sm[12] += sy * tz;
+      sm[13] += sz * tx; sm[14] += sz * ty; sm[15] += sz * tz;
+      sm[18] += 1;
+      sm[19] += o[0]; sm[20] += o[1]; sm[21] += o[2];
+    }
+    if (!rs::solve_from_sums(sm, tr.T, work[lane])) tr.status = 1;
+    a.trials[lane] = tr;
+  }
+  // (7) what the batch leaves behind: generator, shuffle entries, the run of bad samples
+  for (int i = lane; i < 624; i += 64) a.rng->mt[i] = mt[i];
+  const unsigned long long tg = (unsigned long long)tag << 32;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (map.pos[e] >= 0) a.shuf[map.pos[e]] = tg | (unsigned int)map.val[e];
+  if (lane < 3) a.shuf[lane] = tg | (unsigned int)(lane == 0 ? head[0] : (lane == 1 ? head[1] : head[2]));
+  if (lane == 0) {
+    a.rng->idx = idx;
+    rl->ntrials = nt;
+    rl->bad_run = run;
+    rl->dead = dead;
+    rl->batches += 1;
+  }
+}
+
+// countWithinDistance of every model of the batch in one pass over the stored source points (masked by keep_slot),
+// then - in the workgroup that finishes last - the trials are consumed in order under the reference's stopping rule
+__global__ __launch_bounds__(256) void ransac_count_loop_kernel(RansacLoopArgs a, int first) {
+  __shared__ Xf xf[kRansacBatch];
+  __shared__ int ready[kRansacBatch];
+  __shared__ unsigned int cnt[kRansacBatch];
+  __shared__ int s_last;
+  RansacLoopState *rl = a.rl;
+  IcpDevState *st = a.st;
+  if (st->done || !rl->active || rl->settled) return;
+  if (first ? st->hold != 0 : st->hold == 0) return;
+  const int batch = rl->ntrials;
+  if ((int)threadIdx.x < batch) {
+    const RansacTrial &tr = a.trials[threadIdx.x];
+    for (int i = 0; i < 12; ++i) xf[threadIdx.x].m[i] = tr.T[i];
+    ready[threadIdx.x] = tr.status == 0;
+    cnt[threadIdx.x] = 0u;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  if (batch > 0) {
+    unsigned int mine = 0u;  // lane b of each wave keeps the wave's running count for model b
+    const int n = a.n;
+    for (int i0 = blockIdx.x * blockDim.x; i0 < n; i0 += gridDim.x * blockDim.x) {
+      const int i = i0 + (int)threadIdx.x;
+      const bool live = i < n && a.keep_slot[i] != 0;
+      float4 p = make_float4(0.f, 0.f, 0.f, 0.f), q = p;
+      if (live) {
+        p = a.pts[i];
+        q = a.rows[a.nn_slot[i]];
+      }
+      for (int b = 0; b < batch; ++b) {
+        if (!ready[b]) continue;  // block-uniform
+        const float4 m = apply_xf(xf[b], p);
+        const float dx = m.x - q.x, dy = m.y - q.y, dz = m.z - q.z;
+        const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        const unsigned int c = (unsigned int)__popcll(__ballot(live && (double)d < a.inlier_thr2));
+        if (lane == b) mine += c;
+      }
+    }
+    if (lane < batch && mine) atomicAdd(&cnt[lane], mine);
+    __syncthreads();
+    if ((int)threadIdx.x < batch && cnt[threadIdx.x]) atomicAdd(&a.trials[threadIdx.x].count, cnt[threadIdx.x]);
+  }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int t = __hip_atomic_fetch_add((g_u32p)&rl->ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = t == gridDim.x - 1 ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last || threadIdx.x >= 64) return;
+  {
+    // the batch's counts: this rank's, or summed over the ranks (exact: integers below 2^53 as doubles)
+    unsigned int mine_total = 0u;
+    if (lane < batch) mine_total = __hip_atomic_load((g_u32p)&a.trials[lane].count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.comm.world > 1) {
+      double v = (double)mine_total;
+      const unsigned int seq = *a.comm.seq + 1u;
+      const bool ok = comm_allreduce_wave(a.comm, v, kRansacBatch, lane, seq);  // the same count on every rank
+      if (lane == 0) *a.comm.seq = seq;
+      if (!ok) {
+        if (lane == 0) {
+          __hip_atomic_store((g_u32p)&rl->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ransac_comm_failed(a);
+        }
+        return;
+      }
+      mine_total = (unsigned int)llround(v);
+    }
+    if (lane < kRansacBatch) cnt[lane] = mine_total;
+  }
+  if (threadIdx.x != 0) return;
+  __hip_atomic_store((g_u32p)&rl->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // RandomSampleConsensus::computeModel's bookkeeping (ransac.hpp:71-121) over this batch's trials, in order
+  int iterations = rl->iterations, best = rl->best, have = rl->have;
+  unsigned int skipped = rl->skipped;
+  double k = rl->k;
+  const unsigned int max_skip = (unsigned int)min((long long)a.max_trials * 10ll, 0xffffffffll);
+  bool stop = false;
+  int b = 0;
+  for (; b < batch && iterations < k && skipped < max_skip; ++b) {
+    if (!ready[b]) {  // degenerate sample
+      ++skipped;
+      continue;
+    }
+    const int inl = (int)cnt[b];
+    if (inl > best) {
+      best = inl;
+      have = 1;
+      for (int i = 0; i < 16; ++i) rl->Tbest[i] = a.trials[b].T[i];
+      const double w = (double)best / (double)rl->cnt;
+      double p_no = 1.0 - pow(w, 3.0);
+      p_no = fmax(2.220446049250313e-16, p_no);
+      p_no = fmin(1.0 - 2.220446049250313e-16, p_no);
+      k = log(1.0 - 0.99) / log(p_no);  // ransac.hpp:102-107
+    }
+    ++iterations;
+    if (iterations > a.max_trials) {
+      stop = true;
+      break;
+    }
+  }
+  // every model of the batch consumed and the rule still asks for more: no further sample exists once 1000 draws in
+  // a row were bad (computeModel breaks out, ransac.hpp:72-76)
+  if (!stop && b >= batch && rl->dead) stop = true;
+  const bool settled = stop || !(iterations < k && skipped < max_skip);
+  rl->iterations = iterations;
+  rl->best = best;
+  rl->have = have;
+  rl->skipped = skipped;
+  rl->k = k;
+  rl->settled = settled ? 1 : 0;
+  if (settled) rl->trials_last = iterations;
+  else st->hold = 1;
+}
+
+// selectWithinDistance with the best model (ransac.hpp:124) fused with the sums the estimator needs of the inliers
+// (icp.hpp:130-171); no model (computeModel failed) keeps every pair (icp.hpp:128-132).  Then the step's tail.
+template <int EST>
+__global__ __launch_bounds__(64 * ICP_WPB) void ransac_refit_kernel(RansacLoopArgs a, int first, double ox, double oy,
+                                                                     double oz, double *__restrict__ partials,
+                                                                     IcpTail tail, const float4 *__restrict__ tn_slot,
+                                                                     const unsigned char *__restrict__ src_skip,
+                                                                     unsigned char *__restrict__ flags) {
+  __shared__ double lds[ICP_WPB][SumsOf<EST>::n];
+  const RansacLoopState *rl = a.rl;
+  if (a.st->done || !rl->settled) return;
+  if (first ? a.st->hold != 0 : a.st->hold == 0) return;
+  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool have = rl->have != 0;
+  Xf T;
+#pragma unroll
+  for (int j = 0; j < 12; ++j) T.m[j] = rl->Tbest[j];
+  const float nanv = __builtin_nanf("");
+  float4 p = make_float4(nanv, nanv, nanv, 1.f), q = p, m = p;
+  bool paired = false, contrib = false;
+  if (slot < a.n && a.keep_slot[slot] != 0) {
+    p = a.pts[slot];
+    const int js = a.nn_slot[slot];
+    q = a.rows[js];
+    paired = true;
+    if (have) {
+      const float4 mp = apply_xf(T, p);
+      const float dx = mp.x - q.x, dy = mp.y - q.y, dz = mp.z - q.z;
+      const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+      paired = (double)d < a.inlier_thr2;
+    }
+    if (EST && paired) {
+      m = tn_slot[js];
+      contrib = finite3(m) && !(src_skip && src_skip[slot]);
+    }
+  }
+  if (flags && slot < a.n) flags[slot] = paired ? 1 : 0;
+  if (threadIdx.x < SumsOf<EST>::n - SumsOf<EST>::carry0) {  // the carried columns: zeros from this launch
+#pragma unroll
+    for (int w = 0; w < ICP_WPB; ++w) lds[w][SumsOf<EST>::carry0 + threadIdx.x] = 0.0;
+  }
+  if constexpr (EST != 0) {
+    const double aa = (double)__fsub_rn(__fmul_rn(m.z, p.y), __fmul_rn(m.y, p.z));
+    const double bb = (double)__fsub_rn(__fmul_rn(m.x, p.z), __fmul_rn(m.z, p.x));
+    const double cc = (double)__fsub_rn(__fmul_rn(m.y, p.x), __fmul_rn(m.x, p.y));
+    const double nx = m.x, ny = m.y, nz = m.z;
+    float df = __fadd_rn(__fadd_rn(__fmul_rn(m.x, q.x), __fmul_rn(m.y, q.y)), __fmul_rn(m.z, q.z));
+    df = __fsub_rn(__fsub_rn(__fsub_rn(df, __fmul_rn(m.x, p.x)), __fmul_rn(m.y, p.y)), __fmul_rn(m.z, p.z));
+    const double dd = df;
+    {
+      double v[8] = {aa * aa, aa * bb, aa * cc, aa * nx, aa * ny, aa * nz, bb * bb, bb * cc};
+      wave_reduce_to_row(v, contrib, &lds[wib][0], lane);
+    }
+    {
+      double v[8] = {bb * nx, bb * ny, bb * nz, cc * cc, cc * nx, cc * ny, cc * nz, nx * nx};
+      wave_reduce_to_row(v, contrib, &lds[wib][8], lane);
+    }
+    {
+      double v[8] = {nx * ny, nx * nz, ny * ny, ny * nz, nz * nz, aa * dd, bb * dd, cc * dd};
+      wave_reduce_to_row(v, contrib, &lds[wib][16], lane);
+    }
+    __syncthreads();  // the zeros above are in place before the row below overwrites [24..27]
+    {
+      double v[8] = {contrib ? nx * dd : 0.0, contrib ? ny * dd : 0.0, contrib ? nz * dd : 0.0, 1.0, 0.0, 0.0, 0.0, 0.0};
+      wave_reduce_to_row(v, paired, &lds[wib][24], lane);
+    }
+    __syncthreads();
+    icp_step_tail<1>(tail, partials, lds);
+  } else {
+    const double sx = (double)p.x - ox, sy = (double)p.y - oy, sz = (double)p.z - oz;
+    const double tx = (double)q.x - ox, ty = (double)q.y - oy, tz = (double)q.z - oz;
+    {
+      double v[8] = {1.0, sx, sy, sz, tx, ty, tz, sx * tx};
+      wave_reduce_to_row(v, paired, &lds[wib][0], lane);
+    }
+    {
+      double v[8] = {sx * ty, sx * tz, sy * tx, sy * ty, sy * tz, sz * tx, sz * ty, sz * tz};
+      wave_reduce_to_row(v, paired, &lds[wib][8], lane);
+    }
+    __syncthreads();
+    icp_step_tail<0>(tail, partials, lds);
+  }
+}
+
 inline unsigned blocks_for(size_t n, unsigned per) { return (unsigned)((n + per - 1) / per); }
 
 }  // namespace
@@ -1068,27 +1740,29 @@ unsigned icp_step_groups(size_t n) { return (icp_step_blocks(n) + ICP_GROUP - 1)
 void launch_icp_step(const pclmi_tree *t, float4 *d_pts, size_t n, bool apply, const Xf &T, double thr2,
                      int *d_nn, int *d_nn_slot, float *d_dist, const double origin[3], double *d_partials,
                      hipStream_t s, IcpDevState *st, bool have_prev, const IcpTail &tail, const float4 *d_tn_slot,
-                     const unsigned char *d_src_skip) {
+                     const unsigned char *d_src_skip, unsigned char *d_keep_slot) {
   const unsigned blocks = icp_step_blocks(n);
   const bool plane = d_tn_slot != nullptr;  // the point-to-plane loop always walks per lane
+  const bool rsv = d_keep_slot != nullptr;  // the RANSAC loop's step
   const int levels = (plane || nn1_per_lane()) ? lane_nearest_levels(t->M) : 0;
   TimingScope ts(PCLMI_TIMER_ICP_STEP, s);
   const size_t lds_bytes = (size_t)ICP_WPB * levels * 64 * sizeof(float);
-  if (plane)
-    hipLaunchKernelGGL((icp_step_kernel<true, 1>), dim3(blocks), dim3(64 * ICP_WPB), lds_bytes, s, t->view(), d_pts,
-                       (int)n, apply ? 1 : 0, T, (float)thr2, thr2, d_nn, d_nn_slot, d_dist, origin[0], origin[1],
-                       origin[2], d_partials, (const IcpDevState *)st, levels, have_prev ? 1 : 0, tail, d_tn_slot,
-                       d_src_skip);
-  else if (levels > 0)
-    hipLaunchKernelGGL((icp_step_kernel<true, 0>), dim3(blocks), dim3(64 * ICP_WPB), lds_bytes, s, t->view(), d_pts,
-                       (int)n, apply ? 1 : 0, T, (float)thr2, thr2, d_nn, d_nn_slot, d_dist, origin[0], origin[1],
-                       origin[2], d_partials, (const IcpDevState *)st, levels, have_prev ? 1 : 0, tail,
-                       (const float4 *)nullptr, (const unsigned char *)nullptr);
-  else
-    hipLaunchKernelGGL((icp_step_kernel<false, 0>), dim3(blocks), dim3(64 * ICP_WPB), 0, s, t->view(), d_pts, (int)n,
-                       apply ? 1 : 0, T, (float)thr2, thr2, d_nn, d_nn_slot, d_dist, origin[0], origin[1], origin[2],
-                       d_partials, (const IcpDevState *)st, 0, have_prev ? 1 : 0, tail, (const float4 *)nullptr,
-                       (const unsigned char *)nullptr);
+#define PCLMI_STEP_LAUNCH(LANE_, EST_, RS_, LDS_)                                                                      \
+  hipLaunchKernelGGL((icp_step_kernel<LANE_, EST_, RS_>), dim3(blocks), dim3(64 * ICP_WPB), LDS_, s, t->view(), d_pts, \
+                     (int)n, apply ? 1 : 0, T, (float)thr2, thr2, d_nn, d_nn_slot, d_dist, origin[0], origin[1],        \
+                     origin[2], d_partials, (const IcpDevState *)st, levels, have_prev ? 1 : 0, tail, d_tn_slot,        \
+                     d_src_skip, d_keep_slot)
+  if (plane) {
+    if (rsv) PCLMI_STEP_LAUNCH(true, 1, true, lds_bytes);
+    else PCLMI_STEP_LAUNCH(true, 1, false, lds_bytes);
+  } else if (levels > 0) {
+    if (rsv) PCLMI_STEP_LAUNCH(true, 0, true, lds_bytes);
+    else PCLMI_STEP_LAUNCH(true, 0, false, lds_bytes);
+  } else {
+    if (rsv) PCLMI_STEP_LAUNCH(false, 0, true, 0);
+    else PCLMI_STEP_LAUNCH(false, 0, false, 0);
+  }
+#undef PCLMI_STEP_LAUNCH
 }
 
 unsigned pair_reduce_blocks(size_t n) {
@@ -1213,6 +1887,31 @@ void launch_fitness(const float *d_d2, size_t n, double max_range, double *d_out
   unsigned b = blocks_for(n, 256);
   b = b < 1 ? 1 : (b > 2048 ? 2048 : b);
   hipLaunchKernelGGL(fitness_kernel, dim3(b), dim3(256), 0, s, d_d2, (int)n, max_range, d_out2);
+}
+
+void launch_ransac_loop_batch(const RansacLoopArgs &a, int first, int draws, hipStream_t s) {
+  if (draws > kRansacBatch) draws = kRansacBatch;
+  if (first && a.nsb > 0) {
+    hipLaunchKernelGGL(ransac_keep_words_kernel, dim3((unsigned)a.nsb), dim3(kSbRows), 0, s, a);
+    hipLaunchKernelGGL(ransac_keep_count_kernel, dim3((unsigned)std::min(64, (a.nsb + 3) / 4)), dim3(64), 0, s, a);
+  }
+  hipLaunchKernelGGL(ransac_draw_loop_kernel, dim3(1), dim3(64), 0, s, a, first, draws);
+  unsigned b = blocks_for((size_t)a.n, 256);
+  b = b < 1 ? 1 : (b > 1024 ? 1024 : b);
+  hipLaunchKernelGGL(ransac_count_loop_kernel, dim3(b), dim3(256), 0, s, a, first);
+}
+
+void launch_ransac_loop_refit(const RansacLoopArgs &a, const pclmi_tree *t, int first, const double origin[3],
+                              double *d_partials, const IcpTail &tail, const float4 *d_tn_slot,
+                              const unsigned char *d_src_skip, unsigned char *d_flags, hipStream_t s) {
+  (void)t;
+  const unsigned blocks = icp_step_blocks((size_t)a.n);  // the step's grid: the tail's groups are laid out for it
+  if (d_tn_slot)
+    hipLaunchKernelGGL(ransac_refit_kernel<1>, dim3(blocks), dim3(64 * ICP_WPB), 0, s, a, first, origin[0], origin[1],
+                       origin[2], d_partials, tail, d_tn_slot, d_src_skip, d_flags);
+  else
+    hipLaunchKernelGGL(ransac_refit_kernel<0>, dim3(blocks), dim3(64 * ICP_WPB), 0, s, a, first, origin[0], origin[1],
+                       origin[2], d_partials, tail, d_tn_slot, d_src_skip, d_flags);
 }
 
 }  // namespace pclmi

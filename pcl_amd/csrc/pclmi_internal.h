@@ -255,6 +255,9 @@ struct IcpDevState {
   int iterations;
   int converged;
   int last_pairs;
+  int last_inliers;   // pairs the estimator was given (after the RANSAC step; == last_pairs without it)
+  int hold;           // RANSAC loop: an iteration waits for the host to run further batches of trials; every
+                      // speculatively enqueued kernel of later iterations is a no-op meanwhile
   int max_iterations, min_correspondences;
   double fit, tdelta;
   double transformation_epsilon, euclidean_fitness_epsilon;
@@ -272,14 +275,21 @@ struct IcpTail {
   double *gpart = nullptr;          // [sums][ngroups] group sums
   unsigned int *gticket = nullptr;  // [ngroups] arrival tickets, zero between launches
   unsigned int *ticket = nullptr;   // groups finished, zero between launches
-  double *sums_out = nullptr;       // [PCLMI_ICP_NSUMS or _PLANE] the launch's (all-reduced) sums
+  double *sums_out = nullptr;       // [PCLMI_ICP_NSUMS or _PLANE (+ 8 in the RANSAC loop)] the launch's (all-reduced) sums
   IcpDevState *st = nullptr;
   int solve = 0;
   int ngroups = 1;
+  // RANSAC loop, refit launch: the sums that are taken over ALL points (sum d, sum (d - d_prev), point count, origin)
+  // come from the step's (already exchanged) sums instead of this launch's
+  const double *carry = nullptr;
   CommView comm;
 };
+constexpr int kIcpMaxSums = PCLMI_ICP_NSUMS_PLANE + 8;  // the point-to-plane step of the RANSAC loop
 CommView comm_view(const pclmi_comm *c);
 int comm_device(const pclmi_comm *c);
+bool comm_dead(const pclmi_comm *c);        // an exchange timed out: every later one fails at once
+void comm_set_dead(pclmi_comm *c);
+const char *comm_memory(const pclmi_comm *c);  // flavour of the mailbox allocation
 void launch_transform(float4 *d_pts, size_t n, const Xf &T, hipStream_t s);
 void launch_transform_pending(float4 *d_pts, size_t n, IcpDevState *st, hipStream_t s);  // applies st->T iff st->apply
 void launch_icp_solve(const double *d_sums, IcpDevState *st, hipStream_t s, bool plane = false);
@@ -293,7 +303,8 @@ unsigned icp_step_groups(size_t n);
 void launch_icp_step(const pclmi_tree *t, float4 *d_pts, size_t n, bool apply, const Xf &T, double thr2,
                      int *d_nn, int *d_nn_slot, float *d_dist, const double origin[3], double *d_partials,
                      hipStream_t s, IcpDevState *st, bool have_prev, const IcpTail &tail,
-                     const float4 *d_tn_slot = nullptr, const unsigned char *d_src_skip = nullptr);
+                     const float4 *d_tn_slot = nullptr, const unsigned char *d_src_skip = nullptr,
+                     unsigned char *d_keep_slot = nullptr /* non-null: the RANSAC loop's step (8 more sums) */);
 // point-to-plane loop (d_tn_slot != nullptr above): PCLMI_ICP_NSUMS_PLANE sums per launch
 void launch_pair_reduce_plane(const float4 *src, const int *sidx, const float4 *tgt, const int *tidx, const float4 *tn,
                               const unsigned char *src_skip, const unsigned char *flags, size_t n, double *d_partials,
@@ -339,6 +350,52 @@ void launch_ransac_sample_threshold(const double *d_moment_sums, double *d_out, 
 void launch_count_within_batch(const float4 *src, const int *sidx, const float4 *tgt, const int *tidx, size_t n,
                                double thr2, int batch, RansacTrial *d_trials, hipStream_t s,
                                const unsigned char *keep = nullptr);
+// ---- RANSAC rejection inside the device-resident ICP loop (icp_kernels.hip "RANSAC loop") -------------------------
+// Device-side state of the rejection step of ONE iteration (a new, re-seeded model per iteration: icp.hpp:119-120).
+struct RansacLoopState {
+  unsigned int tag;   // entries of the shuffle array carrying this tag belong to the current iteration's model
+  int active;         // this iteration runs the step (>= 3 pairs)
+  int cnt;            // pairs of the iteration (the step's sums)
+  int all_kept;       // every source row has a pair: position in the pair list == row
+  int ntrials;        // models of the current batch
+  int bad_run, dead;  // consecutive bad samples of the trial being drawn; 1000 of them: computeModel gives up
+  int iterations, best, have, settled;  // ransac.hpp:71-121, carried across the batches of the iteration
+  int batches, trials_last;             // diagnostics: batches of this iteration; trials of the last settled one
+  unsigned int skipped, ticket;
+  double k, sthr;
+  float Tbest[16];
+};
+struct RansacLoopArgs {
+  RansacLoopState *rl;
+  IcpDevState *st;
+  const double *sums;  // the step's sums (device memory; already exchanged when sharded)
+  int est;             // 0: SVD estimator, 1: point-to-plane (layout of sums)
+  int n;               // slots of this rank
+  int n_rows;          // rows of the whole source: the pair list's length when every point has a pair
+  int min_corr, max_trials;
+  double inlier_thr2;
+  const RansacRng *rng0;
+  RansacRng *rng;
+  unsigned long long *shuf;  // [n_rows] {tag, value}: shuffled_indices_ without the per-iteration reset
+  const int *inv;            // row -> slot (-1: another rank's row)
+  const float4 *pts;
+  const int *nn_slot;
+  const float4 *rows;        // the target's bucket-slot copy (x, y, z, idx bits)
+  const unsigned char *keep_slot;
+  unsigned long long *keep_bits;  // [nsb * 16] pair mask by row, only built when some row has no pair
+  unsigned int *sb_cnt, *sb_prefix;  // pairs per 1024 rows, exclusive prefix
+  int nsb;
+  RansacTrial *trials;
+  CommView comm;
+};
+// first: the first batch of a new iteration (enqueued speculatively behind the step); otherwise a further batch the
+// host asked for (st->hold).  draws: samples drawn in this batch (<= kRansacBatch)
+void launch_ransac_loop_batch(const RansacLoopArgs &a, int first, int draws, hipStream_t s);
+// refit on the inliers (or on every pair when no model was found) + the iteration's solve, as the step's tail
+void launch_ransac_loop_refit(const RansacLoopArgs &a, const pclmi_tree *t, int first, const double origin[3],
+                              double *d_partials, const IcpTail &tail, const float4 *d_tn_slot,
+                              const unsigned char *d_src_skip, unsigned char *d_flags, hipStream_t s);
+
 void launch_corr_flags(const int *d_nn, const float4 *d_pts, const float4 *d_cloud, const int *d_order, size_t n,
                        double thr2, int *d_tgt_of_orig, unsigned char *d_keep, hipStream_t s,
                        unsigned char *d_keep_slot = nullptr, const float4 *d_rows = nullptr,
