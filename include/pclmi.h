@@ -383,8 +383,13 @@ size_t pclmi_icp_shard_size(const pclmi_icp_ctx *ctx);
 /* pclmi_icp_align over the ranks of `comm` (one process per GPU; every rank calls it with the same arguments and the
  * whole source): target replicated, source sharded as above, one exchange of the PCLMI_ICP_NSUMS sums per iteration
  * inside the step kernel.  final_T and stats are bit-identical on every rank; `aligned` (nullable, n_src rows)
- * receives this rank's own rows only.  RANSAC rejection needs the global pair list: ransac_iterations must be 0
- * (PCLMI_ERR_UNSUPPORTED otherwise).  A communicator of one rank forwards to pclmi_icp_align. */
+ * receives this rank's own rows only.  The RANSAC rejection step (ransac_iterations > 0, the reference's default)
+ * is sharded as well: every rank replays the same sampling stream (same generator, same global pair count), the rank
+ * that owns a sampled row contributes its coordinates, the pair mask (only when some row has no pair), the inlier
+ * counts of a batch of trials and the refit sums are exchanged inside the kernels - same trials, same inliers, same
+ * transform as the single-process align.  The pair mask travels through the communicator's bulk window
+ * (PCLMI_COMM_BULK_MB, default 64: sources up to ~16M rows on 8 ranks; PCLMI_ERR_UNSUPPORTED beyond).
+ * A communicator of one rank forwards to pclmi_icp_align. */
 int pclmi_icp_align_sharded(const pclmi_icp_params *p, const pclmi_tree *target, const float *src, size_t n_src,
                             size_t stride_bytes, const float *guess, pclmi_comm *comm, float final_T[16],
                             float *aligned, pclmi_icp_stats *stats);
@@ -449,7 +454,12 @@ int pclmi_icp_align_observed(const pclmi_icp_params *p, const pclmi_tree *target
  * or pclmi_comm_create_shm(rank, world, name, &comm): the same with the handles exchanged through the POSIX
  * shared-memory object `name` (unique per job; rank 0 creates it).
  * Every rank must issue the same sequence of exchanges (pclmi_comm_allreduce_f64 calls and ICP iterations of
- * contexts the communicator is attached to). */
+ * contexts the communicator is attached to).
+ * After PCLMI_ERR_COMM the communicator is DEAD: a timed-out exchange leaves the ranks' sequence numbers out of step
+ * (a healthy rank finishes exchange s and only times out in s + 1), so every later exchange on it fails at once with
+ * PCLMI_ERR_COMM instead of waiting for the timeout again; destroy it and create a new one on every rank.
+ * The mailbox lives in uncached (else fine-grained) device memory; when neither can be allocated pclmi_comm_begin
+ * fails - coarse-grained memory is not a fallback (the owner's polling loads need not see the peers' writes). */
 #define PCLMI_COMM_HANDLE_BYTES 128
 #define PCLMI_COMM_MAX_RANKS 16
 int pclmi_comm_begin(int rank, int world, pclmi_comm **out, unsigned char handle[PCLMI_COMM_HANDLE_BYTES]);
@@ -459,7 +469,7 @@ int pclmi_comm_rank(const pclmi_comm *c);
 int pclmi_comm_size(const pclmi_comm *c);
 /* How long a rank waits for a peer inside a kernel before giving up (default 10 s). */
 int pclmi_comm_set_timeout(pclmi_comm *c, double seconds);
-/* In-place sum over the ranks of d_buf[0..count) (device memory, count <= 32), enqueued on `stream` as ONE
+/* In-place sum over the ranks of d_buf[0..count) (device memory, count <= 64), enqueued on `stream` as ONE
  * one-workgroup kernel.  pclmi_comm_status synchronises the device and reports PCLMI_ERR_COMM if any exchange of
  * this communicator timed out. */
 int pclmi_comm_allreduce_f64(pclmi_comm *c, double *d_buf, int count, void *stream);

@@ -338,7 +338,16 @@ int pclmi_icp_begin_sharded(const pclmi_tree *target, const float *src, size_t n
     c->groups = icp_step_groups(c->n);  // buffers were sized for the whole source: large enough
   }
   launch_permute(raw.p, c->order.p, c->n, c->pts.p, c->stream);
-  // inv[order[slot]] = slot (RANSAC pair lists; single-process contexts only)
+  if (c->sharded) {
+    // inv[row of the whole source] = this rank's slot, -1 for the other ranks' rows (the sharded RANSAC step: the
+    // owner of a sampled row contributes its coordinates)
+    std::vector<int> h_inv(n_src ? n_src : 1, -1);
+    for (size_t s = 0; s < c->n; ++s) h_inv[c->shard_rows[s]] = (int)s;
+    if (n_src && (hipMemcpyAsync(c->inv.p, h_inv.data(), n_src * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                  hipStreamSynchronize(c->stream) != hipSuccess))
+      return fail(hip_fail(hipGetLastError(), "inv upload", __FILE__, __LINE__));
+  }
+  // inv[order[slot]] = slot (RANSAC pair lists)
   if (!c->sharded) {
     DevBuf<int> ids;
     if ((rc = ids.alloc(n_src))) return fail(rc);
@@ -381,6 +390,8 @@ int pclmi_icp_begin_sharded(const pclmi_tree *target, const float *src, size_t n
 static int icp_step_enqueue(pclmi_icp_ctx *c, double max_correspondence_distance, double *d_sums, void *stream,
                             bool fused, unsigned char *d_keep_slot = nullptr) {
   PCLMI_CHECK(c && d_sums, PCLMI_ERR_INVALID, "NULL argument");
+  PCLMI_CHECK(!(fused && c->comm && comm_dead(c->comm)), PCLMI_ERR_COMM,
+              "an earlier exchange of this communicator timed out: destroy it and create a new one on every rank");
   PCLMI_HIP(hipSetDevice(c->tree->device));
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
   c->user_stream = stream ? s : nullptr;
@@ -558,7 +569,10 @@ int pclmi_icp_state(pclmi_icp_ctx *c, float final_T[16], pclmi_icp_stats *stats)
     std::memcpy(stats->last_transform, h.T, sizeof(h.T));
   }
   if (h.status == PCLMI_ERR_COMM) {
-    set_error("the exchange with the other ranks timed out in iteration %d", h.iterations + 1);
+    if (c->comm) comm_set_dead(c->comm);
+    set_error("the exchange with the other ranks timed out in iteration %d (%s mailbox): the communicator is dead - "
+              "destroy it and create a new one on every rank",
+              h.iterations + 1, c->comm ? comm_memory(c->comm) : "no");
     return PCLMI_ERR_COMM;
   }
   if (h.status == PCLMI_ERR_NOT_ENOUGH) {
@@ -887,6 +901,14 @@ struct RansacLoopBufs {
     a.nsb = nsb;
     a.trials = trials.p;
     a.comm = CommView();
+    if (c->comm) {
+      a.comm = comm_view(c->comm);
+      // the pair mask travels through the communicator's bulk window: two granules per word, per (parity, source rank)
+      PCLMI_CHECK((size_t)nsb * 16 * 2 <= a.comm.bulk_cap, PCLMI_ERR_UNSUPPORTED,
+                  "a source of %zu rows needs a bulk window of %zu MB for the sharded RANSAC step: set "
+                  "PCLMI_COMM_BULK_MB before the communicator is created (or ransac_iterations = 0)",
+                  n_rows, ((size_t)nsb * 16 * 2 * 8 * 2 * (size_t)a.comm.world >> 20) + 1);
+    }
     return PCLMI_OK;
   }
 };
@@ -1046,10 +1068,10 @@ int align_core(const pclmi_icp_params *p, const pclmi_tree *target, const float 
   }
   PCLMI_CHECK(n_src > 0 && src, PCLMI_ERR_INVALID, "empty source cloud");
   const int world = comm ? pclmi_comm_size(comm) : 1;
+  PCLMI_CHECK(world == 1 || !comm_dead(comm), PCLMI_ERR_COMM,
+              "an earlier exchange of this communicator timed out: destroy it and create a new one on every rank");
   PCLMI_CHECK(!on_iteration || world == 1, PCLMI_ERR_UNSUPPORTED,
               "the per-iteration observer sees the whole source: it is not available for a sharded align");
-  PCLMI_CHECK(p->ransac_iterations <= 0 || world == 1, PCLMI_ERR_UNSUPPORTED,
-              "the RANSAC rejection step needs the global pair list: set ransac_iterations = 0 for a sharded align");
   pclmi_icp_ctx *c = nullptr;
   RC(pclmi_icp_begin_sharded(target, src, n_src, stride_bytes, guess, world > 1 ? pclmi_comm_rank(comm) : 0, world, &c));
   if (guess && !is_identity(guess)) std::memcpy(final_T, guess, 16 * sizeof(float));  // icp.hpp:63
@@ -1085,12 +1107,15 @@ int align_core(const pclmi_icp_params *p, const pclmi_tree *target, const float 
     int rc2 = pclmi_icp_end(c, aligned);
     return rc ? rc : rc2;
   }
-  if (!rc && !obs.fn && world == 1) {
-    // the reference's default: RANSAC rejection on.  Device-resident as well (icp_kernels.hip "RANSAC loop")
+  if (!rc && !obs.fn) {
+    // the reference's default: RANSAC rejection on.  Device-resident as well (icp_kernels.hip "RANSAC loop"), on one
+    // GPU or over the ranks of `comm`: every rank draws the same samples (same generator, same pair count), the owner
+    // of a sampled row contributes its coordinates, inlier counts and refit sums are exchanged inside the kernels
+    if (world > 1) rc = pclmi_icp_set_comm(c, comm);
     pclmi_icp_stats st;
     std::memset(&st, 0, sizeof(st));
     set_identity(st.last_transform);
-    rc = ransac_loop_align(c, p, final_T, &st);
+    if (!rc) rc = ransac_loop_align(c, p, final_T, &st);
     if (stats) *stats = st;
     int rc2 = pclmi_icp_end(c, aligned);
     return rc ? rc : rc2;

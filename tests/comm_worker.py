@@ -41,10 +41,10 @@ def main():
     # ---- plain all-reduces: several rounds back to back (both parities, sequence numbers), uneven counts
     res = []
     rng = np.random.default_rng(5)
-    vals = rng.standard_normal((world, 12, 32))  # [rank][round][lane]: every rank knows every rank's inputs
+    vals = rng.standard_normal((world, 12, 64))  # [rank][round][lane]: every rank knows every rank's inputs
     with torch.cuda.stream(stream):
         for rnd in range(12):
-            cnt = 1 + (rnd * 5) % 32
+            cnt = 1 + (rnd * 11) % 64
             buf = torch.from_numpy(vals[rank, rnd].copy()).to(dev)
             comm.allreduce_f64(buf.data_ptr(), cnt, stream.cuda_stream)
             res.append((cnt, buf))
@@ -52,7 +52,7 @@ def main():
     comm.status()
     for rnd, (cnt, buf) in enumerate(res):
         got = buf.cpu().numpy()
-        want = np.zeros(32)
+        want = np.zeros(64)
         for r in range(world):  # rank order, like the device code: bit-identical
             want = want + vals[r, rnd]
         assert np.array_equal(got[:cnt], want[:cnt]), (rnd, got[:cnt], want[:cnt])
@@ -84,9 +84,63 @@ def main():
     rc3, T3, al3, st3 = capi.icp_align_sharded(tree, src, comm, p)
     # the same with TransformationEstimationPointToPlaneLLS: 32 sums per exchange, 6x6 solve in the last workgroup
     rc4, T4, al4, st4 = capi.icp_align_point_to_plane(tree, src, target_normals(tgt), p, comm=comm)
-    np.savez(out, rc4=rc4, T4=T4, al4=al4, it4=st4.iterations, pairs4=st4.last_correspondences, rc3=rc3, T3=T3, al3=al3, it3=st3.iterations, pairs3=st3.last_correspondences, rc=rc, T=T, iterations=st.iterations, converged=st.converged, pairs=st.last_correspondences,
+    # ---- the reference's DEFAULT loop over two ranks: RANSAC rejection on (icp.hpp:113-150)
+    # (a) every row has a pair, 70 % inliers: the first batch of trials does not settle the stopping rule (host-fed
+    #     batches), later iterations do;  (b) a tight distance threshold: some rows have no pair (pair mask exchanged
+    #     through the bulk window, rank / select);  (c) the point-to-plane estimator's refit
+    tgt_r, src_r = ransac_clouds()
+    tree_r = capi.Tree(tgt_r)
+    res = {}
+    for tag, maxd, plane in (("a", 2.0, False), ("b", 0.25, False), ("c", 2.0, True)):
+        pr = capi.icp_default_params()
+        pr.max_iterations, pr.ransac_iterations, pr.max_correspondence_distance = 6, 1000, maxd
+        pr.ransac_outlier_threshold = 0.1
+        if plane:
+            r = capi.icp_align_point_to_plane(tree_r, src_r, target_normals(tgt_r), pr, comm=comm)
+        else:
+            r = capi.icp_align_sharded(tree_r, src_r, comm, pr)
+        res["rc5" + tag], res["T5" + tag], res["al5" + tag] = r[0], r[1], r[2]
+        res["it5" + tag], res["pairs5" + tag], res["inl5" + tag] = r[3].iterations, r[3].last_correspondences, r[3].last_inliers
+    comm.status()
+    np.savez(out, **res, rc4=rc4, T4=T4, al4=al4, it4=st4.iterations, pairs4=st4.last_correspondences, rc3=rc3, T3=T3, al3=al3, it3=st3.iterations, pairs3=st3.last_correspondences, rc=rc, T=T, iterations=st.iterations, converged=st.converged, pairs=st.last_correspondences,
              aligned=aligned, rc2=rc2, T2=T2, it2=st2.iterations, pairs2=st2.last_correspondences)
+    # ---- a rank that skips an exchange: the other one times out ONCE, then the communicator is dead and fails fast
+    import time
+    comm.set_timeout(1.0)
+    if rank == 0:
+        buf = torch.zeros(8, dtype=torch.float64, device=dev)
+        comm.allreduce_f64(buf.data_ptr(), 8, stream.cuda_stream)
+        t0 = time.perf_counter()
+        try:
+            comm.status()
+            raise AssertionError("the exchange with a missing peer must fail")
+        except capi.PclmiError as e:
+            assert e.code == 7, e
+        waited = time.perf_counter() - t0
+        assert 0.5 < waited < 10.0, waited
+        t0 = time.perf_counter()
+        for call in (lambda: comm.allreduce_f64(buf.data_ptr(), 8, stream.cuda_stream),
+                     lambda: capi.icp_align_sharded(tree, src, comm, p)):
+            try:
+                r = call()
+                assert r is not None and r[0] == 7, "a dead communicator must refuse further work"
+            except capi.PclmiError as e:
+                assert e.code == 7, e
+        assert time.perf_counter() - t0 < 0.9, "a dead communicator fails at once, not after another timeout"
+    else:
+        time.sleep(4.0)  # stays alive (its mailbox is mapped by rank 0) while rank 0 times out
     comm.close()
+
+
+def ransac_clouds():
+    """clouds() with 30 % of the source points pushed off the surface: pairs under the distance threshold, but
+    outliers of the rigid model."""
+    tgt, src = clouds()
+    rng = np.random.default_rng(78)
+    src = src[:20_000].copy()
+    bad = rng.random(len(src)) < 0.3
+    src[bad] += (rng.random((int(bad.sum()), 3), dtype=np.float32) - 0.5) * np.float32(1.2)
+    return tgt, src
 
 
 if __name__ == "__main__":

@@ -29,7 +29,7 @@ def test_two_process_allreduce_and_sharded_icp(tmp_path):
     outs = []
     for p in procs:
         try:
-            o, _ = p.communicate(timeout=100)
+            o, _ = p.communicate(timeout=150)
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
@@ -76,3 +76,27 @@ def test_two_process_allreduce_and_sharded_icp(tmp_path):
     own_a = ~np.isnan(a["al4"][:, 0])
     merged = np.where(own_a[:, None], a["al4"], b["al4"])
     assert np.abs(merged[:, :3] - out[:, :3]).max() <= 1e-4
+    # RANSAC rejection on (the reference's default), sharded == single process: same pairs, same inliers (the same
+    # trials were drawn, the same best model chosen), T within 1e-5, bit-identical across the ranks
+    tgt_r, src_r = comm_worker.ransac_clouds()
+    tree_r = capi.Tree(tgt_r)
+    for tag, maxd, plane in (("a", 2.0, False), ("b", 0.25, False), ("c", 2.0, True)):
+        pr = capi.icp_default_params()
+        pr.max_iterations, pr.ransac_iterations, pr.max_correspondence_distance = 6, 1000, maxd
+        pr.ransac_outlier_threshold = 0.1
+        if plane:
+            rc, T, out, st = capi.icp_align_point_to_plane(tree_r, src_r, comm_worker.target_normals(tgt_r), pr)
+        else:
+            rc, T, out, st = capi.icp_align(tree_r, src_r, pr)
+        assert rc == 0 and int(a["rc5" + tag]) == 0 and int(b["rc5" + tag]) == 0, tag
+        assert np.array_equal(a["T5" + tag], b["T5" + tag]), tag
+        assert int(a["it5" + tag]) == st.iterations and int(a["pairs5" + tag]) == st.last_correspondences, tag
+        assert int(a["inl5" + tag]) == st.last_inliers, (tag, int(a["inl5" + tag]), st.last_inliers)
+        assert st.last_inliers < st.last_correspondences, "the rejection step rejects"
+        assert st.last_inliers >= 3
+        if tag == "b":
+            assert st.last_correspondences < len(src_r), "case b must leave rows without a pair"
+        assert np.abs(a["T5" + tag] - T).max() <= 1e-5, tag
+        own_a = ~np.isnan(a["al5" + tag][:, 0])
+        merged = np.where(own_a[:, None], a["al5" + tag], b["al5" + tag])
+        assert np.abs(merged[:, :3] - out[:, :3]).max() <= 1e-4, tag
