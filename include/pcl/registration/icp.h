@@ -56,8 +56,9 @@ class IterativeClosestPoint : public Registration<PointSource, PointTarget> {
 
   /** \brief Not in the reference: run align() over the ranks of a pclmi_comm (one process per GPU, every process
     * calls align() with the same clouds and parameters): the source is sharded over the ranks, every iteration
-    * exchanges the 24 moment sums inside the step kernel (pclmi_icp_align_sharded).  RANSAC rejection must be off
-    * (setRANSACIterations(0)).  Every rank ends with the same final transformation; rows of the output cloud that
+    * exchanges the moment sums inside the step kernel (pclmi_icp_align_sharded); with the RANSAC rejection step on
+    * (the default) every rank replays the same sampling stream and the inlier counts / refit sums are exchanged as
+    * well.  Every rank ends with the same final transformation; rows of the output cloud that
     * belong to other ranks are the input moved by the final transformation in one step.  NULL detaches. */
   void setComm(pclmi_comm *comm) { comm_ = comm; }
 

@@ -2,6 +2,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstddef>
+#include <cstdlib>
 #include <cstring>
 #include <random>
 #include <unordered_map>
@@ -388,7 +389,7 @@ int pclmi_icp_begin_sharded(const pclmi_tree *target, const float *src, size_t n
 // fused: the launch's last workgroup also exchanges the sums with the other ranks (when a communicator is attached)
 // and runs the solve; otherwise it only leaves the rank's sums in d_sums
 static int icp_step_enqueue(pclmi_icp_ctx *c, double max_correspondence_distance, double *d_sums, void *stream,
-                            bool fused, unsigned char *d_keep_slot = nullptr) {
+                            bool fused, unsigned char *d_keep_slot = nullptr, float4 *d_tq = nullptr) {
   PCLMI_CHECK(c && d_sums, PCLMI_ERR_INVALID, "NULL argument");
   PCLMI_CHECK(!(fused && c->comm && comm_dead(c->comm)), PCLMI_ERR_COMM,
               "an earlier exchange of this communicator timed out: destroy it and create a new one on every rank");
@@ -408,7 +409,7 @@ static int icp_step_enqueue(pclmi_icp_ctx *c, double max_correspondence_distance
   if (fused && c->comm) tail.comm = comm_view(c->comm);
   launch_icp_step(c->tree, c->pts.p, c->n, c->pending, make_xf(c->T), thr2, c->nn.p, c->nn_slot.p, c->dist.p, c->origin,
                   c->partials.p, s, c->dev_mode ? c->state.p : nullptr, c->stepped, tail,
-                  c->plane ? c->tn_slot.p : nullptr, c->has_skip ? c->src_skip.p : nullptr, d_keep_slot);
+                  c->plane ? c->tn_slot.p : nullptr, c->has_skip ? c->src_skip.p : nullptr, d_keep_slot, d_tq);
   c->pending = false;
   c->stepped = true;
   PCLMI_HIP(hipGetLastError());
@@ -859,6 +860,7 @@ struct RansacLoopBufs {
   DevBuf<unsigned int> sb_cnt, sb_prefix;
   DevBuf<RansacTrial> trials;
   DevBuf<unsigned char> keep_slot;
+  DevBuf<float4> tq;     // matched target point per slot
   DevBuf<double> sums2;  // the refit launch's sums
   RansacLoopArgs a;
   int init(pclmi_icp_ctx *c, const pclmi_icp_params *p) {
@@ -874,6 +876,7 @@ struct RansacLoopBufs {
     RC(sb_prefix.alloc(nsb));
     RC(trials.alloc(kRansacBatch));
     RC(keep_slot.alloc(c->n));
+    RC(tq.alloc(c->n));
     RC(sums2.alloc(kIcpMaxSums));
     PCLMI_HIP(hipMemsetAsync(rl.p, 0, sizeof(RansacLoopState), s));
     PCLMI_HIP(hipMemsetAsync(shuf.p, 0, n_rows * sizeof(unsigned long long), s));  // tag 0: no entry is current
@@ -895,6 +898,7 @@ struct RansacLoopBufs {
     a.nn_slot = c->nn_slot.p;
     a.rows = (const float4 *)c->tree->d_slot;
     a.keep_slot = keep_slot.p;
+    a.tq = tq.p;
     a.keep_bits = keep_bits.p;
     a.sb_cnt = sb_cnt.p;
     a.sb_prefix = sb_prefix.p;
@@ -917,7 +921,7 @@ struct RansacLoopBufs {
 int ransac_loop_enqueue(pclmi_icp_ctx *c, RansacLoopBufs &rb, const pclmi_icp_params *p, int first) {
   hipStream_t s = c->stream;
   if (first) {
-    RC(icp_step_enqueue(c, p->max_correspondence_distance, c->sums.p, nullptr, true, rb.keep_slot.p));
+    RC(icp_step_enqueue(c, p->max_correspondence_distance, c->sums.p, nullptr, true, rb.keep_slot.p, rb.tq.p));
     launch_ransac_loop_batch(rb.a, 1, 4, s);  // a converged iteration needs ONE trial (99.9 % inliers: k < 1)
   }
   IcpTail tail;
@@ -930,8 +934,12 @@ int ransac_loop_enqueue(pclmi_icp_ctx *c, RansacLoopBufs &rb, const pclmi_icp_pa
   tail.ngroups = (int)c->groups;
   tail.carry = c->sums.p;
   if (c->comm) tail.comm = comm_view(c->comm);
-  launch_ransac_loop_refit(rb.a, c->tree, first, c->origin, c->partials.p, tail, c->plane ? c->tn_slot.p : nullptr,
-                           c->has_skip ? c->src_skip.p : nullptr, nullptr, s);
+  if (first)  // counts + refit sums of the first model + stopping rule + (usually) the solve
+    launch_ransac_loop_first(rb.a, c->origin, c->partials.p, tail, c->plane ? c->tn_slot.p : nullptr,
+                             c->has_skip ? c->src_skip.p : nullptr, s);
+  else  // the rule settled in a host-fed batch, or on another model than the first: refit on that model's inliers
+    launch_ransac_loop_refit(rb.a, c->tree, 0, c->origin, c->partials.p, tail, c->plane ? c->tn_slot.p : nullptr,
+                             c->has_skip ? c->src_skip.p : nullptr, nullptr, s);
   PCLMI_HIP(hipGetLastError());
   return PCLMI_OK;
 }
@@ -950,15 +958,19 @@ int ransac_loop_align(pclmi_icp_ctx *c, const pclmi_icp_params *p, float final_T
     const int now = std::min(chunk, left);
     for (int i = 0; i < now; ++i) RC(ransac_loop_enqueue(c, rb, p, 1));
     IcpDevState h;
+    RansacLoopState hr;
     PCLMI_HIP(hipMemcpyAsync(&h, c->state.p, sizeof(h), hipMemcpyDeviceToHost, s));
+    PCLMI_HIP(hipMemcpyAsync(&hr, rb.rl.p, sizeof(hr), hipMemcpyDeviceToHost, s));
     PCLMI_HIP(hipStreamSynchronize(s));
     const bool stalled = h.hold != 0;
-    while (h.hold && !h.done) {  // further batches for the iteration that waits (ransac.hpp:71-121)
-      launch_ransac_loop_batch(rb.a, 0, kRansacBatch, s);
-      RansacLoopState hr;
-      PCLMI_HIP(hipMemcpyAsync(&hr, rb.rl.p, sizeof(hr), hipMemcpyDeviceToHost, s));
-      PCLMI_HIP(hipStreamSynchronize(s));
-      if (!hr.settled) continue;
+    while (h.hold && !h.done) {  // the iteration that waits: further batches (ransac.hpp:71-121), then the refit
+      if (!hr.settled) {
+        launch_ransac_loop_batch(rb.a, 0, kRansacBatch, s);
+        PCLMI_HIP(hipMemcpyAsync(&hr, rb.rl.p, sizeof(hr), hipMemcpyDeviceToHost, s));
+        PCLMI_HIP(hipMemcpyAsync(&h, c->state.p, sizeof(h), hipMemcpyDeviceToHost, s));
+        PCLMI_HIP(hipStreamSynchronize(s));
+        continue;
+      }
       RC(ransac_loop_enqueue(c, rb, p, 0));
       PCLMI_HIP(hipMemcpyAsync(&h, c->state.p, sizeof(h), hipMemcpyDeviceToHost, s));
       PCLMI_HIP(hipStreamSynchronize(s));
@@ -968,6 +980,19 @@ int ransac_loop_align(pclmi_icp_ctx *c, const pclmi_icp_params *p, float final_T
     if (rc) return rc;
     if (h.done) break;
     chunk = stalled ? 1 : std::min(8, chunk * 2);
+  }
+  if (getenv("PCLMI_RANSAC_TICKS")) {  // development aid: where the last draw kernel spent its time (10 ns ticks)
+    RansacLoopState hr;
+    PCLMI_HIP(hipMemcpy(&hr, rb.rl.p, sizeof(hr), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[pclmi] draw kernel ticks: sthr+reset %llu, prefix %llu, rng %llu, shuffle %llu, lookups %llu, "
+                    "good+fit %llu, write-back %llu\n",
+            hr.dbg[1] - hr.dbg[0], 0ull, hr.dbg[2] - hr.dbg[1], hr.dbg[3] - hr.dbg[2], hr.dbg[4] - hr.dbg[3],
+            hr.dbg[5] - hr.dbg[4], hr.dbg[6] - hr.dbg[5]);
+    IcpDevState h;
+    PCLMI_HIP(hipMemcpy(&h, c->state.p, sizeof(h), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[pclmi] last count+refit launch: last workgroup arrived %llu, sums ready +%llu, solved +%llu (ticks "
+                    "after its first workgroup started)\n",
+            h.ticks[1] - h.ticks[0], h.ticks[2] - h.ticks[1], h.ticks[3] - h.ticks[2]);
   }
   return PCLMI_OK;
 }

@@ -230,6 +230,57 @@ __device__ __forceinline__ double ld_agent(const double *p) {
 }
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// RandomSampleConsensus::computeModel's bookkeeping (ransac.hpp:71-121) over one batch's trials, in order: ready(b)
+// says whether trial b has a model (a degenerate sample is skipped), count(b) its inliers.  Carries the rule's state in
+// rl across the batches of an iteration; returns whether the rule has settled (otherwise st->hold asks the host for
+// another batch).  One lane.
+template <typename ReadyF, typename CountF>
+__device__ __forceinline__ bool ransac_consume(RansacLoopState *rl, IcpDevState *st, const RansacTrial *trials, int batch,
+                                               int max_trials, ReadyF ready, CountF count) {
+  int iterations = rl->iterations, best = rl->best, have = rl->have;
+  unsigned int skipped = rl->skipped;
+  double k = rl->k;
+  const unsigned int max_skip = (unsigned int)min((long long)max_trials * 10ll, 0xffffffffll);
+  bool stop = false;
+  int b = 0;
+  for (; b < batch && iterations < k && skipped < max_skip; ++b) {
+    if (!ready(b)) {  // degenerate sample
+      ++skipped;
+      continue;
+    }
+    const int inl = count(b);
+    if (inl > best) {
+      best = inl;
+      have = 1;
+      rl->best_trial = b;
+      for (int i = 0; i < 16; ++i) rl->Tbest[i] = trials[b].T[i];
+      const double w = (double)best / (double)rl->cnt;
+      double p_no = 1.0 - pow(w, 3.0);
+      p_no = fmax(2.220446049250313e-16, p_no);
+      p_no = fmin(1.0 - 2.220446049250313e-16, p_no);
+      k = log(1.0 - 0.99) / log(p_no);  // ransac.hpp:102-107
+    }
+    ++iterations;
+    if (iterations > max_trials) {
+      stop = true;
+      break;
+    }
+  }
+  // every model of the batch consumed and the rule still asks for more: no further sample exists once 1000 draws in
+  // a row were bad (computeModel breaks out, ransac.hpp:72-76)
+  if (!stop && b >= batch && rl->dead) stop = true;
+  const bool settled = stop || !(iterations < k && skipped < max_skip);
+  rl->iterations = iterations;
+  rl->best = best;
+  rl->have = have;
+  rl->skipped = skipped;
+  rl->k = k;
+  rl->settled = settled ? 1 : 0;
+  if (settled) rl->trials_last = iterations;
+  else st->hold = 1;
+  return settled;
+}
+
 // What the workgroup that finishes a step's reduction goes on to do (IcpTail, see icp_step_tail).
 constexpr int ICP_GROUP = 64;  // workgroups per reduction group
 
@@ -251,7 +302,9 @@ __device__ __forceinline__ double tail_column_sum(const double *col_base, int cn
 // workgroup happens to be last), exchanges them with the other ranks when a communicator is attached (comm_dev.hpp),
 // writes sums_out and, when asked, runs the solve.  Nobody waits for anybody inside the GPU: a workgroup that is not
 // last simply ends.  Returns to the caller only in the last workgroup's first wave... never: everything happens here.
-template <int EST, bool RS = false>
+// DECIDE: the first batch of the RANSAC loop (ransac_first_kernel): columns cnt0.. of the sums are the inlier counts
+// of the batch's models; the stopping rule runs here and the solve only when it settles on the refit sums' model
+template <int EST, bool RS = false, bool DECIDE = false>
 __device__ __forceinline__ void icp_step_tail(const IcpTail &tail, double *__restrict__ partials,
                                               double (*lds)[SumsOf<EST, RS>::n]) {
   constexpr int NS = SumsOf<EST, RS>::n;  // shadows the SVD loop's count
@@ -334,6 +387,28 @@ __device__ __forceinline__ void icp_step_tail(const IcpTail &tail, double *__res
         st->status = PCLMI_ERR_COMM;
         st->done = 1;
       } else if (tail.solve) {
+        if constexpr (DECIDE) {
+          RansacLoopState *rl = tail.rl;
+          bool solve_now = true;  // fewer than 3 pairs: no rejection step, the sums are over every pair
+          if (rl->active) {
+            constexpr int cnt0 = EST ? 32 : 24;
+            const int batch = rl->ntrials;
+            int b0 = 0;  // the model the refit sums belong to: the first trial that has one
+            while (b0 < batch && tail.trials[b0].status != 0) ++b0;
+            const bool settled = ransac_consume(rl, st, tail.trials, batch, tail.max_trials,
+                                                [&](int b) { return tail.trials[b].status == 0; },
+                                                [&](int b) { return (int)llround(fin[cnt0 + b]); });
+            solve_now = settled && rl->have && rl->best_trial == b0;
+            if (settled && !solve_now) {  // settled on another model (or on none): the host enqueues the refit
+              rl->need_refit = 1;
+              st->hold = 1;
+            }
+          }
+          if (!solve_now) {
+            st->ticks[3] = (unsigned long long)wall_clock64();
+            return;
+          }
+        }
         icp_solve_body<EST>(fin, st, svd_work, &sin);
         st->last_inliers = st->last_pairs;
         if (step_pairs >= 0) {
@@ -366,7 +441,8 @@ __global__ __launch_bounds__(64 * ICP_WPB) __attribute__((amdgpu_waves_per_eu(8,
                                                                  int have_prev, IcpTail tail,
                                                                  const float4 *__restrict__ tn_slot,
                                                                  const unsigned char *__restrict__ src_skip,
-                                                                 unsigned char *__restrict__ keep_slot) {
+                                                                 unsigned char *__restrict__ keep_slot,
+                                                                 float4 *__restrict__ tq) {
   static_assert(LANE || !EST, "the point-to-plane loop reads the target normals by bucket slot");
   extern __shared__ float far_lds[];
   __shared__ double lds[ICP_WPB][SumsOf<EST, RS>::n];
@@ -457,6 +533,7 @@ __global__ __launch_bounds__(64 * ICP_WPB) __attribute__((amdgpu_waves_per_eu(8,
         if ((double)d < thr2) {  // strict, icp.hpp:93
           q = rows[bslot];
           paired = true;
+          if (RS) tq[slot] = q;  // the rejection step's passes read the matched point in storage order
           if (EST) {
             m = tn_slot[bslot];
             contrib = finite3(m) && !(src_skip && src_skip[slot]);
@@ -743,39 +820,44 @@ __global__ __launch_bounds__(256) void count_within_kernel(const float4 *__restr
 // sample_dist_thresh_ = (mean of the square roots of the eigenvalues of the source points' covariance)^2
 // (computeSampleDistanceThreshold, sac_model_registration.h:257-279; cyclic Jacobi stands in for pcl::eigen33).
 // m: the sums of moment_reduce_kernel (second moments 0..5, first moments 6..8, count 9).
+// one Jacobi rotation of the symmetric 3x3 (c00 c01 c02; . c11 c12; . . c22) that zeroes element (P, Q); R is the
+// third index.  Compile-time indices: everything stays in registers.
+template <int P, int Q>
+__device__ __forceinline__ void sym3_rotate(double (&d)[3], double (&o)[3]) {
+  // o[0] = c01, o[1] = c02, o[2] = c12; element (p, q) lives at o[p + q - 1]
+  constexpr int R = 3 - P - Q;
+  constexpr int ipq = P + Q - 1, ipr = P + R - 1, iqr = Q + R - 1;
+  const double apq = o[ipq];
+  if (fabs(apq) < 1e-300) return;
+  const double theta = (d[Q] - d[P]) / (2.0 * apq);
+  const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+  const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+  d[P] -= t * apq;
+  d[Q] += t * apq;
+  o[ipq] = 0.0;
+  const double arp = o[ipr], arq = o[iqr];
+  o[ipr] = cs * arp - sn * arq;
+  o[iqr] = sn * arp + cs * arq;
+}
+
 __device__ __forceinline__ double sample_threshold_from_moments(const double *m) {
   const double inv_n = 1.0 / m[9];
   double a[9];
+#pragma unroll
   for (int i = 0; i < 9; ++i) a[i] = m[i] * inv_n;
-  const double C00 = a[0] - a[6] * a[6], C01 = a[1] - a[6] * a[7], C02 = a[2] - a[6] * a[8],
-               C11 = a[3] - a[7] * a[7], C12 = a[4] - a[7] * a[8], C22 = a[5] - a[8] * a[8];
-  double c[9] = {C00, C01, C02, C01, C11, C12, C02, C12, C22};
+  double d[3] = {a[0] - a[6] * a[6], a[3] - a[7] * a[7], a[5] - a[8] * a[8]};
+  double o[3] = {a[1] - a[6] * a[7], a[2] - a[6] * a[8], a[4] - a[7] * a[8]};
   for (int sweep = 0; sweep < 60; ++sweep) {
     // converged: the off-diagonal part is below the last bit of the diagonal, further rotations change nothing
-    const double off = fabs(c[1]) + fabs(c[2]) + fabs(c[5]);
-    if (off <= 1e-22 * (fabs(c[0]) + fabs(c[4]) + fabs(c[8])) || off < 1e-300) break;
-    for (int p = 0; p < 2; ++p)
-      for (int q = p + 1; q < 3; ++q) {
-        const double apq = c[p * 3 + q];
-        if (fabs(apq) < 1e-300) continue;
-        const double theta = (c[q * 3 + q] - c[p * 3 + p]) / (2.0 * apq);
-        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-        const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
-        for (int k = 0; k < 3; ++k) {
-          const double akp = c[k * 3 + p], akq = c[k * 3 + q];
-          c[k * 3 + p] = cs * akp - sn * akq;
-          c[k * 3 + q] = sn * akp + cs * akq;
-        }
-        for (int k = 0; k < 3; ++k) {
-          const double apk = c[p * 3 + k], aqk = c[q * 3 + k];
-          c[p * 3 + k] = cs * apk - sn * aqk;
-          c[q * 3 + k] = sn * apk + cs * aqk;
-        }
-      }
+    const double off = fabs(o[0]) + fabs(o[1]) + fabs(o[2]);
+    if (off <= 1e-22 * (fabs(d[0]) + fabs(d[1]) + fabs(d[2])) || off < 1e-300) break;
+    sym3_rotate<0, 1>(d, o);
+    sym3_rotate<0, 2>(d, o);
+    sym3_rotate<1, 2>(d, o);
   }
-  const double ev[3] = {c[0], c[4], c[8]};
   double sthr = 0.0;
-  for (int i = 0; i < 3; ++i) sthr += sqrt(ev[i] > 0 ? ev[i] : 0.0);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) sthr += sqrt(d[i] > 0 ? d[i] : 0.0);
   sthr /= 3.0;
   return sthr * sthr;
 }
@@ -1105,6 +1187,16 @@ __global__ __launch_bounds__(kSbRows) void ransac_keep_words_kernel(RansacLoopAr
     k = sl >= 0 && a.keep_slot[sl] != 0;
   }
   const unsigned long long w = __ballot(k);
+  __shared__ int c16[kSbRows / 64];
+  if (a.comm.world == 1) {  // one rank: the block's pair count is final (sharded: ransac_keep_count_kernel)
+    if ((threadIdx.x & 63) == 0) c16[threadIdx.x >> 6] = __popcll(w);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int t = 0;
+      for (int i = 0; i < kSbRows / 64; ++i) t += c16[i];
+      a.sb_cnt[blockIdx.x] = (unsigned int)t;
+    }
+  }
   if ((threadIdx.x & 63) == 0) {
     a.keep_bits[row >> 6] = w;  // nsb * 16 words are allocated
     if (a.comm.world > 1) {
@@ -1224,24 +1316,42 @@ __device__ __forceinline__ void map_put(ShufMap &m, int j, int v, int lane) {
 }
 
 // position in the pair list -> source row: the pos-th set bit of the pair mask
-__device__ __forceinline__ int select_row(const RansacLoopArgs &a, int pos) {
+// lpre: the exclusive prefix in LDS (up to kSbLds blocks of 1024 rows), else nullptr: read from a.sb_prefix
+constexpr int kSbLds = 4096;
+__device__ __forceinline__ int select_row(const RansacLoopArgs &a, const unsigned int *lpre, int pos) {
   int lo = 0, hi = a.nsb - 1;  // last block whose prefix is <= pos
+  auto pre = [&](int i) {
+    return lpre ? (int)lpre[i]
+                : (int)__hip_atomic_load((g_u32p)&a.sb_prefix[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
-    if ((int)__hip_atomic_load((g_u32p)&a.sb_prefix[mid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= pos) lo = mid;
+    if (pre(mid) <= pos) lo = mid;
     else hi = mid - 1;
   }
-  int rem = pos - (int)__hip_atomic_load((g_u32p)&a.sb_prefix[lo], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const unsigned long long *w = a.keep_bits + (size_t)lo * (kSbRows / 64);
-  int wi = 0;
-  unsigned long long bits = 0;
-  for (; wi < kSbRows / 64; ++wi) {
-    bits = w[wi];
-    const int c = __popcll(bits);
-    if (rem < c) break;
-    rem -= c;
+  int rem = pos - pre(lo);
+  const ulonglong2 *w2 = reinterpret_cast<const ulonglong2 *>(a.keep_bits + (size_t)lo * (kSbRows / 64));
+  unsigned long long wv[kSbRows / 64];
+#pragma unroll
+  for (int i = 0; i < kSbRows / 128; ++i) {  // the block's 16 words, all loads in flight
+    const ulonglong2 t = w2[i];
+    wv[2 * i] = t.x;
+    wv[2 * i + 1] = t.y;
   }
-  if (wi == kSbRows / 64) return -1;  // cannot happen for pos < the pair count
+  int wi = kSbRows / 64;
+  unsigned long long bits = 0;
+  bool found = false;
+#pragma unroll
+  for (int i = 0; i < kSbRows / 64; ++i) {
+    const int c = __popcll(wv[i]);
+    if (!found && rem < c) {
+      found = true;
+      wi = i;
+      bits = wv[i];
+    }
+    if (!found) rem -= c;
+  }
+  if (!found) return -1;  // cannot happen for pos < the pair count
   for (; rem > 0; --rem) bits &= bits - 1;
   return lo * kSbRows + wi * 64 + (__ffsll((long long)bits) - 1);
 }
@@ -1253,6 +1363,7 @@ __global__ __launch_bounds__(64) void ransac_draw_loop_kernel(RansacLoopArgs a, 
   __shared__ int trial_of[kRansacBatch];
   __shared__ double work[kRansacBatch][42];
   __shared__ double s_sthr;
+  __shared__ unsigned int lpre[kSbLds];
   RansacLoopState *rl = a.rl;
   IcpDevState *st = a.st;
   const int lane = threadIdx.x;
@@ -1261,6 +1372,13 @@ __global__ __launch_bounds__(64) void ransac_draw_loop_kernel(RansacLoopArgs a, 
   const int i_pairs = a.est ? 27 : 0;
   int cnt;
   double sthr;
+  if (lane == 0) rl->dbg[0] = (unsigned long long)wall_clock64();
+  // the generator's state: loads issued first, in flight while the threshold below is computed
+  const RansacRng *rin = first ? a.rng0 : a.rng;
+  unsigned int mtv[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) mtv[i] = lane + 64 * i < 624 ? rin->mt[lane + 64 * i] : 0u;
+  int idx = rin->idx;
   const unsigned int tag = first ? rl->tag + 1u : rl->tag;  // read before lane 0 advances it
   const int run0 = first ? 0 : rl->bad_run, dead0 = first ? 0 : rl->dead;
   if (first) {
@@ -1292,6 +1410,8 @@ __global__ __launch_bounds__(64) void ransac_draw_loop_kernel(RansacLoopArgs a, 
       rl->iterations = 0;
       rl->best = -INT32_MAX;
       rl->have = 0;
+      rl->best_trial = -1;
+      rl->need_refit = 0;
       rl->settled = cnt >= 3 ? 0 : 1;
       rl->batches = 0;
       rl->skipped = 0u;
@@ -1307,11 +1427,17 @@ __global__ __launch_bounds__(64) void ransac_draw_loop_kernel(RansacLoopArgs a, 
   }
   const bool all_kept = cnt == a.n_rows;
   const bool fresh = first != 0;
-  if (first && !all_kept) {  // exclusive prefix of the per-1024-row pair counts
+  const bool pre_lds = a.nsb <= kSbLds;
+  if (!all_kept && (first || pre_lds)) {  // exclusive prefix of the per-1024-row pair counts
+    // first batch: from the counts; a further batch with the prefix in LDS: the same again (cheap)
     const int chunk = (a.nsb + 63) / 64;
     const int b0 = lane * chunk, b1 = min(a.nsb, b0 + chunk);
+    if (pre_lds) {
+      for (int i = lane; i < a.nsb; i += 64) lpre[i] = a.sb_cnt[i];  // independent loads, all in flight
+      __syncthreads();
+    }
     unsigned int sum = 0;
-    for (int i = b0; i < b1; ++i) sum += a.sb_cnt[i];
+    for (int i = b0; i < b1; ++i) sum += pre_lds ? lpre[i] : a.sb_cnt[i];
     unsigned int incl = sum;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -1320,15 +1446,22 @@ __global__ __launch_bounds__(64) void ransac_draw_loop_kernel(RansacLoopArgs a, 
     }
     unsigned int run = incl - sum;
     for (int i = b0; i < b1; ++i) {
-      const unsigned int c = a.sb_cnt[i];
-      a.sb_prefix[i] = run;
+      const unsigned int c = pre_lds ? lpre[i] : a.sb_cnt[i];
+      if (pre_lds) lpre[i] = run;
+      else a.sb_prefix[i] = run;
       run += c;
     }
-    __threadfence();  // select_row (other lanes of this wave) reads the prefix with agent-scope loads
+    if (!pre_lds) __threadfence();  // select_row (other lanes of this wave) reads the prefix with agent-scope loads
+    __syncthreads();
   }
-  const RansacRng *rin = first ? a.rng0 : a.rng;
-  for (int i = lane; i < 624; i += 64) mt[i] = rin->mt[i];
-  int idx = rin->idx;
+#define PCLMI_DSTAMP(i)                                                    \
+  do {                                                                    \
+    if (lane == 0) rl->dbg[i] = (unsigned long long)wall_clock64();       \
+  } while (0)
+  PCLMI_DSTAMP(1);
+#pragma unroll
+  for (int i = 0; i < 10; ++i)
+    if (lane + 64 * i < 624) mt[lane + 64 * i] = mtv[i];
   __syncthreads();
   // (1) the generator's numbers of the whole batch: they depend on nothing but the pair count
   for (int d = 0; d < draws; ++d)
@@ -1337,6 +1470,7 @@ __global__ __launch_bounds__(64) void ransac_draw_loop_kernel(RansacLoopArgs a, 
       if (lane == 0) jpos[d][i] = i + (int)(r % (unsigned int)(cnt - i));
     }
   __syncthreads();
+  PCLMI_DSTAMP(2);
   // (2) the far ends' entries as earlier batches of this iteration left them, all loads in flight together
   for (int t = lane; t < 3 * draws; t += 64) {
     const int j = jpos[t / 3][t % 3];
@@ -1349,6 +1483,7 @@ __global__ __launch_bounds__(64) void ransac_draw_loop_kernel(RansacLoopArgs a, 
   }
   int head[3] = {0, 1, 2};
   if (!fresh)
+#pragma unroll
     for (int i = 0; i < 3; ++i) {
       const unsigned long long g = a.shuf[i];
       if ((unsigned int)(g >> 32) == tag) head[i] = (int)(unsigned int)g;
@@ -1360,7 +1495,8 @@ __global__ __launch_bounds__(64) void ransac_draw_loop_kernel(RansacLoopArgs a, 
   for (int e = 0; e < 4; ++e) map.pos[e] = -1, map.val[e] = 0;
   map.count = 0;
   for (int d = 0; d < draws; ++d) {
-    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {  // (unrolled: head[] stays in registers)
       const int j = jpos[d][i];
       if (j < 3) {
         const int t = head[i];
@@ -1384,15 +1520,16 @@ __global__ __launch_bounds__(64) void ransac_draw_loop_kernel(RansacLoopArgs a, 
     }
   }
   __syncthreads();
+  PCLMI_DSTAMP(3);
   // (4) the sampled pairs' coordinates, one lookup chain per lane
   for (int t = lane; t < 3 * draws; t += 64) {
     const int pos = dpos[t / 3][t % 3];
-    const int row = all_kept ? pos : select_row(a, pos);
+    const int row = all_kept ? pos : select_row(a, pre_lds ? lpre : nullptr, pos);
     const int sl = row >= 0 ? a.inv[row] : -1;
     float4 p = make_float4(0.f, 0.f, 0.f, 0.f), q = p;
     if (sl >= 0) {
       p = a.pts[sl];
-      q = a.rows[a.nn_slot[sl]];
+      q = a.tq[sl];
     }
     six[t / 3][2 * (t % 3)] = p;
     six[t / 3][2 * (t % 3) + 1] = q;
@@ -1429,6 +1566,7 @@ __global__ __launch_bounds__(64) void ransac_draw_loop_kernel(RansacLoopArgs a, 
     }
     __syncthreads();
   }
+  PCLMI_DSTAMP(4);
   // (5) isSampleGood (sac_model_registration.hpp:47-60); a trial is a good sample, at most 1000 draws apart
   bool good = false;
   if (lane < draws) {
@@ -1477,6 +1615,8 @@ __global__ __launch_bounds__(64) void ransac_draw_loop_kernel(RansacLoopArgs a, 
     if (!rs::solve_from_sums(sm, tr.T, work[lane])) tr.status = 1;
     a.trials[lane] = tr;
   }
+  __builtin_amdgcn_s_waitcnt(0);
+  PCLMI_DSTAMP(5);
   // (7) what the batch leaves behind: generator, shuffle entries, the run of bad samples
   for (int i = lane; i < 624; i += 64) a.rng->mt[i] = mt[i];
   const unsigned long long tg = (unsigned long long)tag << 32;
@@ -1491,6 +1631,9 @@ __global__ __launch_bounds__(64) void ransac_draw_loop_kernel(RansacLoopArgs a, 
     rl->dead = dead;
     rl->batches += 1;
   }
+  __builtin_amdgcn_s_waitcnt(0);
+  PCLMI_DSTAMP(6);
+#undef PCLMI_DSTAMP
 }
 
 // countWithinDistance of every model of the batch in one pass over the stored source points (masked by keep_slot),
@@ -1522,7 +1665,7 @@ __global__ __launch_bounds__(256) void ransac_count_loop_kernel(RansacLoopArgs a
       float4 p = make_float4(0.f, 0.f, 0.f, 0.f), q = p;
       if (live) {
         p = a.pts[i];
-        q = a.rows[a.nn_slot[i]];
+        q = a.tq[i];
       }
       for (int b = 0; b < batch; ++b) {
         if (!ready[b]) continue;  // block-uniform
@@ -1535,12 +1678,15 @@ __global__ __launch_bounds__(256) void ransac_count_loop_kernel(RansacLoopArgs a
     }
     if (lane < batch && mine) atomicAdd(&cnt[lane], mine);
     __syncthreads();
-    if ((int)threadIdx.x < batch && cnt[threadIdx.x]) atomicAdd(&a.trials[threadIdx.x].count, cnt[threadIdx.x]);
+    if ((int)threadIdx.x < batch && cnt[threadIdx.x])
+      __hip_atomic_fetch_add((g_u32p)&a.trials[threadIdx.x].count, cnt[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  __threadfence();
-  __syncthreads();
+  // the hand-off of icp_step_tail: agent-scope atomics (performed at the device's coherence point), the issuing wave
+  // (wave 0: batch <= 64) drains them, then ITS lane 0 takes the ticket - no cache write-back / invalidate, which an
+  // acquire-release ticket would cost every one of the 1024 workgroups
+  drain_stores();
   if (threadIdx.x == 0) {
-    const unsigned int t = __hip_atomic_fetch_add((g_u32p)&rl->ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned int t = __hip_atomic_fetch_add((g_u32p)&rl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = t == gridDim.x - 1 ? 1 : 0;
   }
   __syncthreads();
@@ -1567,47 +1713,9 @@ __global__ __launch_bounds__(256) void ransac_count_loop_kernel(RansacLoopArgs a
   }
   if (threadIdx.x != 0) return;
   __hip_atomic_store((g_u32p)&rl->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // RandomSampleConsensus::computeModel's bookkeeping (ransac.hpp:71-121) over this batch's trials, in order
-  int iterations = rl->iterations, best = rl->best, have = rl->have;
-  unsigned int skipped = rl->skipped;
-  double k = rl->k;
-  const unsigned int max_skip = (unsigned int)min((long long)a.max_trials * 10ll, 0xffffffffll);
-  bool stop = false;
-  int b = 0;
-  for (; b < batch && iterations < k && skipped < max_skip; ++b) {
-    if (!ready[b]) {  // degenerate sample
-      ++skipped;
-      continue;
-    }
-    const int inl = (int)cnt[b];
-    if (inl > best) {
-      best = inl;
-      have = 1;
-      for (int i = 0; i < 16; ++i) rl->Tbest[i] = a.trials[b].T[i];
-      const double w = (double)best / (double)rl->cnt;
-      double p_no = 1.0 - pow(w, 3.0);
-      p_no = fmax(2.220446049250313e-16, p_no);
-      p_no = fmin(1.0 - 2.220446049250313e-16, p_no);
-      k = log(1.0 - 0.99) / log(p_no);  // ransac.hpp:102-107
-    }
-    ++iterations;
-    if (iterations > a.max_trials) {
-      stop = true;
-      break;
-    }
-  }
-  // every model of the batch consumed and the rule still asks for more: no further sample exists once 1000 draws in
-  // a row were bad (computeModel breaks out, ransac.hpp:72-76)
-  if (!stop && b >= batch && rl->dead) stop = true;
-  const bool settled = stop || !(iterations < k && skipped < max_skip);
-  rl->iterations = iterations;
-  rl->best = best;
-  rl->have = have;
-  rl->skipped = skipped;
-  rl->k = k;
-  rl->settled = settled ? 1 : 0;
-  if (settled) rl->trials_last = iterations;
-  else st->hold = 1;
+  if (ransac_consume(rl, st, a.trials, batch, a.max_trials, [&](int b) { return ready[b] != 0; },
+                     [&](int b) { return (int)cnt[b]; }))
+    rl->need_refit = 1;
 }
 
 // selectWithinDistance with the best model (ransac.hpp:124) fused with the sums the estimator needs of the inliers
@@ -1620,79 +1728,197 @@ __global__ __launch_bounds__(64 * ICP_WPB) void ransac_refit_kernel(RansacLoopAr
                                                                      unsigned char *__restrict__ flags) {
   __shared__ double lds[ICP_WPB][SumsOf<EST>::n];
   const RansacLoopState *rl = a.rl;
-  if (a.st->done || !rl->settled) return;
+  if (a.st->done || !rl->settled || !rl->need_refit) return;  // (the first batch's fused sums usually did it)
   if (first ? a.st->hold != 0 : a.st->hold == 0) return;
   const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
   const bool have = rl->have != 0;
   Xf T;
 #pragma unroll
   for (int j = 0; j < 12; ++j) T.m[j] = rl->Tbest[j];
-  const float nanv = __builtin_nanf("");
-  float4 p = make_float4(nanv, nanv, nanv, 1.f), q = p, m = p;
-  bool paired = false, contrib = false;
-  if (slot < a.n && a.keep_slot[slot] != 0) {
-    p = a.pts[slot];
-    const int js = a.nn_slot[slot];
-    q = a.rows[js];
-    paired = true;
-    if (have) {
-      const float4 mp = apply_xf(T, p);
-      const float dx = mp.x - q.x, dy = mp.y - q.y, dz = mp.z - q.z;
-      const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-      paired = (double)d < a.inlier_thr2;
-    }
-    if (EST && paired) {
-      m = tn_slot[js];
-      contrib = finite3(m) && !(src_skip && src_skip[slot]);
-    }
-  }
-  if (flags && slot < a.n) flags[slot] = paired ? 1 : 0;
   if (threadIdx.x < SumsOf<EST>::n - SumsOf<EST>::carry0) {  // the carried columns: zeros from this launch
 #pragma unroll
     for (int w = 0; w < ICP_WPB; ++w) lds[w][SumsOf<EST>::carry0 + threadIdx.x] = 0.0;
   }
-  if constexpr (EST != 0) {
-    const double aa = (double)__fsub_rn(__fmul_rn(m.z, p.y), __fmul_rn(m.y, p.z));
-    const double bb = (double)__fsub_rn(__fmul_rn(m.x, p.z), __fmul_rn(m.z, p.x));
-    const double cc = (double)__fsub_rn(__fmul_rn(m.y, p.x), __fmul_rn(m.x, p.y));
-    const double nx = m.x, ny = m.y, nz = m.z;
-    float df = __fadd_rn(__fadd_rn(__fmul_rn(m.x, q.x), __fmul_rn(m.y, q.y)), __fmul_rn(m.z, q.z));
-    df = __fsub_rn(__fsub_rn(__fsub_rn(df, __fmul_rn(m.x, p.x)), __fmul_rn(m.y, p.y)), __fmul_rn(m.z, p.z));
-    const double dd = df;
-    {
-      double v[8] = {aa * aa, aa * bb, aa * cc, aa * nx, aa * ny, aa * nz, bb * bb, bb * cc};
-      wave_reduce_to_row(v, contrib, &lds[wib][0], lane);
+  // every thread adds up its slots (a few: the grid is a fraction of the points, so that the reduction, the hand-off
+  // of the partial sums and the arrival ticket are paid once per workgroup and not once per 256 points)
+  constexpr int NA = EST ? 28 : 16;
+  double acc[NA];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) acc[j] = 0.0;
+  for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < a.n; slot += gridDim.x * blockDim.x) {
+    bool paired = false;
+    float4 p = make_float4(0.f, 0.f, 0.f, 1.f), q = p;
+    int js = 0;
+    if (a.keep_slot[slot] != 0) {
+      p = a.pts[slot];
+      if (EST) js = a.nn_slot[slot];
+      q = a.tq[slot];
+      paired = true;
+      if (have) {
+        const float4 mp = apply_xf(T, p);
+        const float dx = mp.x - q.x, dy = mp.y - q.y, dz = mp.z - q.z;
+        const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        paired = (double)d < a.inlier_thr2;
+      }
     }
-    {
-      double v[8] = {bb * nx, bb * ny, bb * nz, cc * cc, cc * nx, cc * ny, cc * nz, nx * nx};
-      wave_reduce_to_row(v, contrib, &lds[wib][8], lane);
+    if (flags) flags[slot] = paired ? 1 : 0;
+    if (!paired) continue;
+    if constexpr (EST != 0) {
+      acc[27] += 1.0;
+      const float4 m = tn_slot[js];
+      if (!finite3(m) || (src_skip && src_skip[slot])) continue;
+      const double v[6] = {(double)__fsub_rn(__fmul_rn(m.z, p.y), __fmul_rn(m.y, p.z)),
+                           (double)__fsub_rn(__fmul_rn(m.x, p.z), __fmul_rn(m.z, p.x)),
+                           (double)__fsub_rn(__fmul_rn(m.y, p.x), __fmul_rn(m.x, p.y)),
+                           (double)m.x, (double)m.y, (double)m.z};
+      float df = __fadd_rn(__fadd_rn(__fmul_rn(m.x, q.x), __fmul_rn(m.y, q.y)), __fmul_rn(m.z, q.z));
+      df = __fsub_rn(__fsub_rn(__fsub_rn(df, __fmul_rn(m.x, p.x)), __fmul_rn(m.y, p.y)), __fmul_rn(m.z, p.z));
+      const double dd = df;
+      int o = 0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int k = r; k < 6; ++k) acc[o++] += v[r] * v[k];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) acc[21 + r] += v[r] * dd;
+    } else {
+      const double sx = (double)p.x - ox, sy = (double)p.y - oy, sz = (double)p.z - oz;
+      const double tx = (double)q.x - ox, ty = (double)q.y - oy, tz = (double)q.z - oz;
+      acc[0] += 1.0;
+      acc[1] += sx; acc[2] += sy; acc[3] += sz;
+      acc[4] += tx; acc[5] += ty; acc[6] += tz;
+      acc[7] += sx * tx; acc[8] += sx * ty; acc[9] += sx * tz;
+      acc[10] += sy * tx; acc[11] += sy * ty; acc[12] += sy * tz;
+      acc[13] += sz * tx; acc[14] += sz * ty; acc[15] += sz * tz;
     }
-    {
-      double v[8] = {nx * ny, nx * nz, ny * ny, ny * nz, nz * nz, aa * dd, bb * dd, cc * dd};
-      wave_reduce_to_row(v, contrib, &lds[wib][16], lane);
-    }
-    __syncthreads();  // the zeros above are in place before the row below overwrites [24..27]
-    {
-      double v[8] = {contrib ? nx * dd : 0.0, contrib ? ny * dd : 0.0, contrib ? nz * dd : 0.0, 1.0, 0.0, 0.0, 0.0, 0.0};
-      wave_reduce_to_row(v, paired, &lds[wib][24], lane);
-    }
-    __syncthreads();
-    icp_step_tail<1>(tail, partials, lds);
-  } else {
-    const double sx = (double)p.x - ox, sy = (double)p.y - oy, sz = (double)p.z - oz;
-    const double tx = (double)q.x - ox, ty = (double)q.y - oy, tz = (double)q.z - oz;
-    {
-      double v[8] = {1.0, sx, sy, sz, tx, ty, tz, sx * tx};
-      wave_reduce_to_row(v, paired, &lds[wib][0], lane);
-    }
-    {
-      double v[8] = {sx * ty, sx * tz, sy * tx, sy * ty, sy * tz, sz * tx, sz * ty, sz * tz};
-      wave_reduce_to_row(v, paired, &lds[wib][8], lane);
-    }
-    __syncthreads();
-    icp_step_tail<0>(tail, partials, lds);
   }
+  __syncthreads();  // the zeros of the carried columns are in place
+#pragma unroll
+  for (int g0 = 0; g0 < NA; g0 += 8) {
+    double v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = g0 + j < NA ? acc[g0 + j] : 0.0;
+    wave_reduce_to_row(v, true, &lds[wib][g0], lane);
+  }
+  __syncthreads();
+  icp_step_tail<EST>(tail, partials, lds);
+}
+
+// The first batch of an iteration in ONE pass (the usual case: a converging align's first trial settles the stopping
+// rule): the inlier counts of the batch's (at most kRansacFirst) models AND the refit sums over the inliers of the
+// first of them go through the step's tail together - reduction, ONE exchange when sharded, then the stopping rule and,
+// when it settles on that first model, the solve.  Otherwise the host-fed batches / ransac_refit_kernel take over.
+constexpr int kRansacFirst = 4;
+template <int EST>
+__global__ __launch_bounds__(64 * ICP_WPB) __attribute__((amdgpu_waves_per_eu(EST ? 2 : 4, EST ? 3 : 4))) void ransac_first_kernel(RansacLoopArgs a, double ox, double oy, double oz,
+                                                                     double *__restrict__ partials, IcpTail tail,
+                                                                     const float4 *__restrict__ tn_slot,
+                                                                     const unsigned char *__restrict__ src_skip) {
+  __shared__ double lds[ICP_WPB][SumsOf<EST, true>::n];
+  __shared__ Xf xf[kRansacFirst];
+  __shared__ int ready[kRansacFirst];
+  const RansacLoopState *rl = a.rl;
+  if (a.st->done || a.st->hold) return;
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.st->ticks[0] = (unsigned long long)wall_clock64();
+  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  const bool active = rl->active != 0;
+  const int batch = active ? min(rl->ntrials, kRansacFirst) : 0;
+  if ((int)threadIdx.x < kRansacFirst) {
+    const bool r = (int)threadIdx.x < batch && a.trials[threadIdx.x].status == 0;
+    ready[threadIdx.x] = r ? 1 : 0;
+    for (int i = 0; i < 12; ++i) xf[threadIdx.x].m[i] = r ? a.trials[threadIdx.x].T[i] : 0.f;
+  }
+  constexpr int NS_ = SumsOf<EST, true>::n;
+  for (int j = threadIdx.x; j < ICP_WPB * NS_; j += blockDim.x) lds[j / NS_][j % NS_] = 0.0;
+  __syncthreads();
+  int b0 = 0;  // the model the refit sums are taken over: the first trial that has one (none: every pair, icp.hpp:128-132)
+  while (b0 < batch && !ready[b0]) ++b0;
+  const bool have0 = b0 < batch;
+  constexpr int NA = EST ? 28 : 16;
+  double acc[NA];
+  double cntv[kRansacFirst];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) acc[j] = 0.0;
+#pragma unroll
+  for (int b = 0; b < kRansacFirst; ++b) cntv[b] = 0.0;
+  constexpr int IT = EST ? 2 : 4;  // slots per thread and round, their loads in flight together (128 VGPRs: 4 workgroups per CU)
+  for (int base = blockIdx.x * (blockDim.x * IT) + threadIdx.x; base - (int)threadIdx.x < a.n;
+       base += gridDim.x * blockDim.x * IT) {
+    bool kp[IT];
+    float4 p[IT], q[IT];
+    int js[IT];
+#pragma unroll
+    for (int j = 0; j < IT; ++j) {
+      const int slot = base + j * (int)blockDim.x;
+      kp[j] = slot < a.n && a.keep_slot[slot] != 0;
+    }
+#pragma unroll
+    for (int j = 0; j < IT; ++j) {  // (not under kp: these loads go out together with the mask's)
+      const int slot = min(base + j * (int)blockDim.x, a.n - 1);
+      p[j] = a.pts[slot];
+      q[j] = a.tq[slot];
+      js[j] = EST ? a.nn_slot[slot] : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < IT; ++j) {
+      if (!kp[j]) continue;
+      bool in0 = !have0;
+#pragma unroll
+      for (int b = 0; b < kRansacFirst; ++b) {
+        if (!ready[b]) continue;  // block-uniform
+        const float4 mp = apply_xf(xf[b], p[j]);
+        const float dx = mp.x - q[j].x, dy = mp.y - q[j].y, dz = mp.z - q[j].z;
+        const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        const bool in = (double)d < a.inlier_thr2;
+        cntv[b] += in ? 1.0 : 0.0;
+        if (b == b0) in0 = in;
+      }
+      if (!in0) continue;
+      if constexpr (EST != 0) {
+        acc[27] += 1.0;
+        const int slot = base + j * (int)blockDim.x;
+        const float4 m = tn_slot[js[j]];
+        if (!finite3(m) || (src_skip && src_skip[slot])) continue;
+        const float4 pp = p[j], qq = q[j];
+        const double v[6] = {(double)__fsub_rn(__fmul_rn(m.z, pp.y), __fmul_rn(m.y, pp.z)),
+                             (double)__fsub_rn(__fmul_rn(m.x, pp.z), __fmul_rn(m.z, pp.x)),
+                             (double)__fsub_rn(__fmul_rn(m.y, pp.x), __fmul_rn(m.x, pp.y)),
+                             (double)m.x, (double)m.y, (double)m.z};
+        float df = __fadd_rn(__fadd_rn(__fmul_rn(m.x, qq.x), __fmul_rn(m.y, qq.y)), __fmul_rn(m.z, qq.z));
+        df = __fsub_rn(__fsub_rn(__fsub_rn(df, __fmul_rn(m.x, pp.x)), __fmul_rn(m.y, pp.y)), __fmul_rn(m.z, pp.z));
+        const double dd = df;
+        int o = 0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+          for (int k = r; k < 6; ++k) acc[o++] += v[r] * v[k];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) acc[21 + r] += v[r] * dd;
+      } else {
+        const double sx = (double)p[j].x - ox, sy = (double)p[j].y - oy, sz = (double)p[j].z - oz;
+        const double tx = (double)q[j].x - ox, ty = (double)q[j].y - oy, tz = (double)q[j].z - oz;
+        acc[0] += 1.0;
+        acc[1] += sx; acc[2] += sy; acc[3] += sz;
+        acc[4] += tx; acc[5] += ty; acc[6] += tz;
+        acc[7] += sx * tx; acc[8] += sx * ty; acc[9] += sx * tz;
+        acc[10] += sy * tx; acc[11] += sy * ty; acc[12] += sy * tz;
+        acc[13] += sz * tx; acc[14] += sz * ty; acc[15] += sz * tz;
+      }
+    }
+  }
+#pragma unroll
+  for (int g0 = 0; g0 < NA; g0 += 8) {
+    double v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = g0 + j < NA ? acc[g0 + j] : 0.0;
+    wave_reduce_to_row(v, true, &lds[wib][g0], lane);
+  }
+  {
+    double v[8] = {cntv[0], cntv[1], cntv[2], cntv[3], 0.0, 0.0, 0.0, 0.0};
+    wave_reduce_to_row(v, true, &lds[wib][EST ? 32 : 24], lane);
+  }
+  __syncthreads();
+  icp_step_tail<EST, true, true>(tail, partials, lds);
 }
 
 inline unsigned blocks_for(size_t n, unsigned per) { return (unsigned)((n + per - 1) / per); }
@@ -1740,7 +1966,7 @@ unsigned icp_step_groups(size_t n) { return (icp_step_blocks(n) + ICP_GROUP - 1)
 void launch_icp_step(const pclmi_tree *t, float4 *d_pts, size_t n, bool apply, const Xf &T, double thr2,
                      int *d_nn, int *d_nn_slot, float *d_dist, const double origin[3], double *d_partials,
                      hipStream_t s, IcpDevState *st, bool have_prev, const IcpTail &tail, const float4 *d_tn_slot,
-                     const unsigned char *d_src_skip, unsigned char *d_keep_slot) {
+                     const unsigned char *d_src_skip, unsigned char *d_keep_slot, float4 *d_tq) {
   const unsigned blocks = icp_step_blocks(n);
   const bool plane = d_tn_slot != nullptr;  // the point-to-plane loop always walks per lane
   const bool rsv = d_keep_slot != nullptr;  // the RANSAC loop's step
@@ -1751,7 +1977,7 @@ void launch_icp_step(const pclmi_tree *t, float4 *d_pts, size_t n, bool apply, c
   hipLaunchKernelGGL((icp_step_kernel<LANE_, EST_, RS_>), dim3(blocks), dim3(64 * ICP_WPB), LDS_, s, t->view(), d_pts, \
                      (int)n, apply ? 1 : 0, T, (float)thr2, thr2, d_nn, d_nn_slot, d_dist, origin[0], origin[1],        \
                      origin[2], d_partials, (const IcpDevState *)st, levels, have_prev ? 1 : 0, tail, d_tn_slot,        \
-                     d_src_skip, d_keep_slot)
+                     d_src_skip, d_keep_slot, d_tq)
   if (plane) {
     if (rsv) PCLMI_STEP_LAUNCH(true, 1, true, lds_bytes);
     else PCLMI_STEP_LAUNCH(true, 1, false, lds_bytes);
@@ -1893,25 +2119,49 @@ void launch_ransac_loop_batch(const RansacLoopArgs &a, int first, int draws, hip
   if (draws > kRansacBatch) draws = kRansacBatch;
   if (first && a.nsb > 0) {
     hipLaunchKernelGGL(ransac_keep_words_kernel, dim3((unsigned)a.nsb), dim3(kSbRows), 0, s, a);
-    hipLaunchKernelGGL(ransac_keep_count_kernel, dim3((unsigned)std::min(64, (a.nsb + 3) / 4)), dim3(64), 0, s, a);
+    if (a.comm.world > 1)
+      hipLaunchKernelGGL(ransac_keep_count_kernel, dim3((unsigned)std::min(64, (a.nsb + 3) / 4)), dim3(64), 0, s, a);
   }
   hipLaunchKernelGGL(ransac_draw_loop_kernel, dim3(1), dim3(64), 0, s, a, first, draws);
+  if (first) return;  // the first batch's models are counted by launch_ransac_loop_first
   unsigned b = blocks_for((size_t)a.n, 256);
   b = b < 1 ? 1 : (b > 1024 ? 1024 : b);
   hipLaunchKernelGGL(ransac_count_loop_kernel, dim3(b), dim3(256), 0, s, a, first);
+}
+
+void launch_ransac_loop_first(const RansacLoopArgs &a, const double origin[3], double *d_partials, const IcpTail &tail,
+                              const float4 *d_tn_slot, const unsigned char *d_src_skip, hipStream_t s) {
+  // one round of workgroups: 4 per CU x 256 CUs are resident at 128 VGPRs
+  unsigned blocks = blocks_for((size_t)a.n, 64 * ICP_WPB * (d_tn_slot ? 2 : 4));
+  const unsigned cap = d_tn_slot ? 512u : 1024u;  // (the point-to-plane instance: 2 workgroups per CU)
+  blocks = blocks < 1 ? 1 : (blocks > cap ? cap : blocks);
+  IcpTail tl = tail;
+  tl.ngroups = (int)((blocks + ICP_GROUP - 1) / ICP_GROUP);
+  tl.rl = a.rl;
+  tl.trials = a.trials;
+  tl.max_trials = a.max_trials;
+  if (d_tn_slot)
+    hipLaunchKernelGGL(ransac_first_kernel<1>, dim3(blocks), dim3(64 * ICP_WPB), 0, s, a, origin[0], origin[1], origin[2],
+                       d_partials, tl, d_tn_slot, d_src_skip);
+  else
+    hipLaunchKernelGGL(ransac_first_kernel<0>, dim3(blocks), dim3(64 * ICP_WPB), 0, s, a, origin[0], origin[1], origin[2],
+                       d_partials, tl, d_tn_slot, d_src_skip);
 }
 
 void launch_ransac_loop_refit(const RansacLoopArgs &a, const pclmi_tree *t, int first, const double origin[3],
                               double *d_partials, const IcpTail &tail, const float4 *d_tn_slot,
                               const unsigned char *d_src_skip, unsigned char *d_flags, hipStream_t s) {
   (void)t;
-  const unsigned blocks = icp_step_blocks((size_t)a.n);  // the step's grid: the tail's groups are laid out for it
+  // a fraction of the step's grid (every thread adds up a few slots); the tail's groups follow the grid
+  const unsigned blocks = std::min(icp_step_blocks((size_t)a.n), 1024u);
+  IcpTail tl = tail;
+  tl.ngroups = (int)((blocks + ICP_GROUP - 1) / ICP_GROUP);
   if (d_tn_slot)
     hipLaunchKernelGGL(ransac_refit_kernel<1>, dim3(blocks), dim3(64 * ICP_WPB), 0, s, a, first, origin[0], origin[1],
-                       origin[2], d_partials, tail, d_tn_slot, d_src_skip, d_flags);
+                       origin[2], d_partials, tl, d_tn_slot, d_src_skip, d_flags);
   else
     hipLaunchKernelGGL(ransac_refit_kernel<0>, dim3(blocks), dim3(64 * ICP_WPB), 0, s, a, first, origin[0], origin[1],
-                       origin[2], d_partials, tail, d_tn_slot, d_src_skip, d_flags);
+                       origin[2], d_partials, tl, d_tn_slot, d_src_skip, d_flags);
 }
 
 }  // namespace pclmi

@@ -282,6 +282,12 @@ struct IcpTail {
   // RANSAC loop, refit launch: the sums that are taken over ALL points (sum d, sum (d - d_prev), point count, origin)
   // come from the step's (already exchanged) sums instead of this launch's
   const double *carry = nullptr;
+  // RANSAC loop, first batch of an iteration (ransac_first_kernel): the launch's sums also hold the inlier counts of
+  // the batch's models; the tail applies the stopping rule and solves only when the rule settles on the model whose
+  // inliers the refit sums were taken over
+  struct RansacLoopState *rl = nullptr;
+  const struct RansacTrial *trials = nullptr;
+  int max_trials = 0;
   CommView comm;
 };
 constexpr int kIcpMaxSums = PCLMI_ICP_NSUMS_PLANE + 8;  // the point-to-plane step of the RANSAC loop
@@ -304,7 +310,8 @@ void launch_icp_step(const pclmi_tree *t, float4 *d_pts, size_t n, bool apply, c
                      int *d_nn, int *d_nn_slot, float *d_dist, const double origin[3], double *d_partials,
                      hipStream_t s, IcpDevState *st, bool have_prev, const IcpTail &tail,
                      const float4 *d_tn_slot = nullptr, const unsigned char *d_src_skip = nullptr,
-                     unsigned char *d_keep_slot = nullptr /* non-null: the RANSAC loop's step (8 more sums) */);
+                     unsigned char *d_keep_slot = nullptr /* non-null: the RANSAC loop's step (8 more sums) */,
+                     float4 *d_tq = nullptr /* with d_keep_slot: the matched target point per slot */);
 // point-to-plane loop (d_tn_slot != nullptr above): PCLMI_ICP_NSUMS_PLANE sums per launch
 void launch_pair_reduce_plane(const float4 *src, const int *sidx, const float4 *tgt, const int *tidx, const float4 *tn,
                               const unsigned char *src_skip, const unsigned char *flags, size_t n, double *d_partials,
@@ -360,10 +367,13 @@ struct RansacLoopState {
   int ntrials;        // models of the current batch
   int bad_run, dead;  // consecutive bad samples of the trial being drawn; 1000 of them: computeModel gives up
   int iterations, best, have, settled;  // ransac.hpp:71-121, carried across the batches of the iteration
+  int best_trial;                       // index of the best model inside the batch that produced it
+  int need_refit;                       // settled, but not by the model the first batch's fused refit sums belong to
   int batches, trials_last;             // diagnostics: batches of this iteration; trials of the last settled one
   unsigned int skipped, ticket;
   double k, sthr;
   float Tbest[16];
+  unsigned long long dbg[12];  // development aid (PCLMI_RANSAC_TICKS=1): wall_clock64 stamps of the last draw kernel
 };
 struct RansacLoopArgs {
   RansacLoopState *rl;
@@ -381,6 +391,7 @@ struct RansacLoopArgs {
   const float4 *pts;
   const int *nn_slot;
   const float4 *rows;        // the target's bucket-slot copy (x, y, z, idx bits)
+  const float4 *tq;          // per slot: the matched target point (written by the step where keep_slot is set)
   const unsigned char *keep_slot;
   unsigned long long *keep_bits;  // [nsb * 16] pair mask by row, only built when some row has no pair
   unsigned int *sb_cnt, *sb_prefix;  // pairs per 1024 rows, exclusive prefix
@@ -391,6 +402,9 @@ struct RansacLoopArgs {
 // first: the first batch of a new iteration (enqueued speculatively behind the step); otherwise a further batch the
 // host asked for (st->hold).  draws: samples drawn in this batch (<= kRansacBatch)
 void launch_ransac_loop_batch(const RansacLoopArgs &a, int first, int draws, hipStream_t s);
+// the first batch's counts fused with the refit sums of its first model, the stopping rule and (usually) the solve
+void launch_ransac_loop_first(const RansacLoopArgs &a, const double origin[3], double *d_partials, const IcpTail &tail,
+                              const float4 *d_tn_slot, const unsigned char *d_src_skip, hipStream_t s);
 // refit on the inliers (or on every pair when no model was found) + the iteration's solve, as the step's tail
 void launch_ransac_loop_refit(const RansacLoopArgs &a, const pclmi_tree *t, int first, const double origin[3],
                               double *d_partials, const IcpTail &tail, const float4 *d_tn_slot,

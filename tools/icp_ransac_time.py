@@ -10,7 +10,7 @@ from pcl_amd import capi
 tgt, src, T_true = bench.icp_clouds()
 tree = capi.Tree(tgt)
 res = {}
-for iters in (1, 5, 1, 5):
+for iters in (1, 5, 10, 30, 1, 5, 10, 30):
     p = capi.icp_default_params()
     p.max_iterations = iters
     p.transformation_epsilon = 0.0
@@ -22,4 +22,4 @@ for iters in (1, 5, 1, 5):
     rc, T, _, st = capi.icp_align(tree, src, p)
     res[iters] = time.perf_counter() - t0
     print("iterations %d: %.2f ms (rc %d, inliers %d)" % (iters, res[iters] * 1e3, rc, st.last_inliers), flush=True)
-print("per iteration: %.3f ms" % ((res[5] - res[1]) / 4 * 1e3))
+print("per iteration, 2..5: %.3f ms; 11..30 (converged): %.3f ms" % ((res[5] - res[1]) / 4 * 1e3, (res[30] - res[10]) / 20 * 1e3))
