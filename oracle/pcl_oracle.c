@@ -507,7 +507,12 @@ static void mat4_mul(const float A[16], const float B[16], float C[16]) {
  * Eigen does so that "column 2" below is the smallest one).  A = U diag(s) V'.           */
 static void svd3(const float A[9], float U[9], float S[3], float V[9]) {
   float a[9];
-  memcpy(a, A, sizeof(a));
+  /* Eigen::JacobiSVD works on matrix / max|coefficient| (JacobiSVD.h "m_scaledMatrix"): without it the products
+   * alpha * beta below overflow fp32 for the H of a few 100k points of magnitude 1e3 and no rotation is applied */
+  float scale = 0.f;
+  for (int i = 0; i < 9; ++i) scale = fabsf(A[i]) > scale ? fabsf(A[i]) : scale;
+  if (!(scale > 0.f)) scale = 1.f;
+  for (int i = 0; i < 9; ++i) a[i] = A[i] / scale;
   float v[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   for (int sweep = 0; sweep < 60; ++sweep) {
     float off = 0.f;
@@ -555,6 +560,7 @@ static void svd3(const float A[9], float U[9], float S[3], float V[9]) {
       U[r * 3 + c] = S[c] > 0.f ? a[r * 3 + ord[c]] / S[c] : 0.f;
     }
   }
+  for (int c = 0; c < 3; ++c) S[c] *= scale; /* (the rank tests below compare singular values with each other) */
   /* rank-deficient input (3-point RANSAC samples give rank 2): complete U to a full
    * orthonormal basis, which is what ComputeFullU returns */
   float tiny = S[0] * 1e-6f;

@@ -1367,22 +1367,32 @@ __global__ __launch_bounds__(64) void ransac_draw_loop_kernel(RansacLoopArgs a, 
   RansacLoopState *rl = a.rl;
   IcpDevState *st = a.st;
   const int lane = threadIdx.x;
-  if (st->done) return;
-  if (first ? st->hold != 0 : (st->hold == 0 || rl->settled != 0)) return;
   const int i_pairs = a.est ? 27 : 0;
-  int cnt;
-  double sthr;
-  if (lane == 0) rl->dbg[0] = (unsigned long long)wall_clock64();
-  // the generator's state: loads issued first, in flight while the threshold below is computed
+  // everything this wave needs from memory before it can start: ONE round trip (the loads below do not depend on
+  // each other; the early returns come after them)
   const RansacRng *rin = first ? a.rng0 : a.rng;
   unsigned int mtv[10];
 #pragma unroll
   for (int i = 0; i < 10; ++i) mtv[i] = lane + 64 * i < 624 ? rin->mt[lane + 64 * i] : 0u;
   int idx = rin->idx;
-  const unsigned int tag = first ? rl->tag + 1u : rl->tag;  // read before lane 0 advances it
-  const int run0 = first ? 0 : rl->bad_run, dead0 = first ? 0 : rl->dead;
+  const int st_done = st->done, st_hold = st->hold, rl_settled = rl->settled;
+  const unsigned int tag_in = rl->tag;
+  const int run_in = rl->bad_run, dead_in = rl->dead, cnt_in = rl->cnt;
+  const double sthr_in = rl->sthr, pairs_in = a.sums[i_pairs];
+  double mom_in = 0.0;  // lane i < 9: moment i of the paired source points
+  {
+    const int mom1 = a.est ? 31 : 1, mom2 = a.est ? 34 : 24;
+    if (lane < 9) mom_in = a.sums[lane < 6 ? mom2 + lane : mom1 + (lane - 6)];
+  }
+  if (st_done) return;
+  if (first ? st_hold != 0 : (st_hold == 0 || rl_settled != 0)) return;
+  int cnt;
+  double sthr;
+  if (lane == 0) rl->dbg[0] = (unsigned long long)wall_clock64();
+  const unsigned int tag = first ? tag_in + 1u : tag_in;
+  const int run0 = first ? 0 : run_in, dead0 = first ? 0 : dead_in;
   if (first) {
-    const long long c64 = llround(a.sums[i_pairs]);
+    const long long c64 = llround(pairs_in);
     cnt = (int)c64;
     if (c64 < (long long)a.min_corr) {  // icp.hpp:103-108, before the rejection step
       if (lane == 0) {
@@ -1393,12 +1403,11 @@ __global__ __launch_bounds__(64) void ransac_draw_loop_kernel(RansacLoopArgs a, 
       }
       return;
     }
+    double m[10];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) m[i] = __shfl(mom_in, i);
+    m[9] = pairs_in;
     if (lane == 0) {
-      const int mom1 = a.est ? 31 : 1, mom2 = a.est ? 34 : 24;
-      double m[10];
-      for (int i = 0; i < 6; ++i) m[i] = a.sums[mom2 + i];
-      for (int i = 0; i < 3; ++i) m[6 + i] = a.sums[mom1 + i];
-      m[9] = a.sums[i_pairs];
       s_sthr = cnt >= 3 ? sample_threshold_from_moments(m) : 0.0;
       rl->tag = tag;
       rl->cnt = cnt;
@@ -1422,8 +1431,8 @@ __global__ __launch_bounds__(64) void ransac_draw_loop_kernel(RansacLoopArgs a, 
     __syncthreads();
     sthr = s_sthr;
   } else {
-    cnt = rl->cnt;
-    sthr = rl->sthr;
+    cnt = cnt_in;
+    sthr = sthr_in;
   }
   const bool all_kept = cnt == a.n_rows;
   const bool fresh = first != 0;
@@ -1489,12 +1498,46 @@ __global__ __launch_bounds__(64) void ransac_draw_loop_kernel(RansacLoopArgs a, 
       if ((unsigned int)(g >> 32) == tag) head[i] = (int)(unsigned int)g;
     }
   __syncthreads();
-  // (3) drawIndexSample (sac_model.h:401-412) replayed: shuf[i] <-> shuf[i + rnd() % (cnt - i)], i = 0, 1, 2
+  // (3) drawIndexSample (sac_model.h:401-412) replayed: shuf[i] <-> shuf[i + rnd() % (cnt - i)], i = 0, 1, 2.
+  // The swaps of a batch only depend on each other where two of them touch one position.  With far ends that are
+  // all different and all beyond the three heads (the rule on a large cloud: 192 positions out of a million) every
+  // sample is simply what its far ends held, and each far end receives the head of the draw before - no replay.
+  __shared__ int htab[512];
+  for (int i = lane; i < 512; i += 64) htab[i] = -1;
+  __syncthreads();
+  bool conflict = false;
+  for (int t = lane; t < 3 * draws; t += 64) {
+    const int j = jpos[t / 3][t % 3];
+    if (j < 3) {
+      conflict = true;
+    } else {
+      unsigned int h = ((unsigned int)j * 2654435761u) >> 23;
+      for (int probe = 0; probe < 512; ++probe) {
+        const int old = atomicCAS(&htab[h], -1, j);
+        if (old == -1) break;
+        if (old == j) {
+          conflict = true;
+          break;
+        }
+        h = (h + 1u) & 511u;
+      }
+    }
+  }
+  const bool replay = __any(conflict) != 0;
+  const int head0[3] = {head[0], head[1], head[2]};
   ShufMap map;
 #pragma unroll
   for (int e = 0; e < 4; ++e) map.pos[e] = -1, map.val[e] = 0;
   map.count = 0;
-  for (int d = 0; d < draws; ++d) {
+  if (!replay) {
+    for (int t = lane; t < 3 * draws; t += 64) dpos[t / 3][t % 3] = gval[t / 3][t % 3];
+    if (draws > 0) {
+      head[0] = gval[draws - 1][0];
+      head[1] = gval[draws - 1][1];
+      head[2] = gval[draws - 1][2];
+    }
+  }
+  for (int d = 0; replay && d < draws; ++d) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {  // (unrolled: head[] stays in registers)
       const int j = jpos[d][i];
@@ -1623,6 +1666,12 @@ __global__ __launch_bounds__(64) void ransac_draw_loop_kernel(RansacLoopArgs a, 
 #pragma unroll
   for (int e = 0; e < 4; ++e)
     if (map.pos[e] >= 0) a.shuf[map.pos[e]] = tg | (unsigned int)map.val[e];
+  if (!replay)  // far end (d, i) received the head of the draw before
+    for (int t = lane; t < 3 * draws; t += 64) {
+      const int d = t / 3, i = t % 3;
+      const int v = d == 0 ? (i == 0 ? head0[0] : (i == 1 ? head0[1] : head0[2])) : gval[d - 1][i];
+      a.shuf[jpos[d][i]] = tg | (unsigned int)v;
+    }
   if (lane < 3) a.shuf[lane] = tg | (unsigned int)(lane == 0 ? head[0] : (lane == 1 ? head[1] : head[2]));
   if (lane == 0) {
     a.rng->idx = idx;

@@ -195,6 +195,57 @@ PCLMI_HD bool polar_rotation(const double H[9], double R[9]) {
   return true;
 }
 
+// H of (numerical) rank 2 - RANSAC's three-point samples, clouds on one plane - or with a tiny negative determinant
+// fails polar_rotation's first test and used to take the Jacobi SVD (~8 us of one lane's fp64 latency, on the critical
+// path of every batch of RANSAC trials).  R = V diag(1, 1, det(V U')) U' (the reflection fix of
+// transformation_estimation_svd.hpp:156-160 acts on the smallest singular value's pair) is also the polar factor of
+//   H + s sigma ns nt'     ns / nt: unit normals of H's column / row space, sigma ~ ||H||, s = +-1 so that det > 0
+// because that matrix has the same first two singular pairs and (ns, nt) as the third with a positive determinant.
+// ns / nt are the largest cross product of two columns / rows.  Returns false (caller takes the SVD) for rank <= 1.
+PCLMI_HD bool rank2_completion(const double H[9], double Hc[9]) {
+  double f2 = 0.0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) f2 += H[i] * H[i];
+  if (!(f2 > 0.0)) return false;
+  // only where the third singular value is noise (|det| = s1 s2 s3 below 1e-12 ||H||^3): a full-rank H with a negative
+  // determinant (a genuine reflection) has its own third singular pair, which the cross products below do not give
+  if (!(fabs(det3(H)) <= 1e-12 * f2 * sqrt(f2))) return false;
+  double ns[3] = {0, 0, 0}, nt[3] = {0, 0, 0}, bs = -1.0, bt = -1.0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const int b = (a + 1) % 3;
+    // columns a, b of H (span of the demeaned source points) and rows a, b (span of the target points)
+    const double ca[3] = {H[0 * 3 + a], H[1 * 3 + a], H[2 * 3 + a]}, cb[3] = {H[0 * 3 + b], H[1 * 3 + b], H[2 * 3 + b]};
+    const double ra[3] = {H[a * 3 + 0], H[a * 3 + 1], H[a * 3 + 2]}, rb[3] = {H[b * 3 + 0], H[b * 3 + 1], H[b * 3 + 2]};
+    const double xs[3] = {ca[1] * cb[2] - ca[2] * cb[1], ca[2] * cb[0] - ca[0] * cb[2], ca[0] * cb[1] - ca[1] * cb[0]};
+    const double xt[3] = {ra[1] * rb[2] - ra[2] * rb[1], ra[2] * rb[0] - ra[0] * rb[2], ra[0] * rb[1] - ra[1] * rb[0]};
+    const double qs = xs[0] * xs[0] + xs[1] * xs[1] + xs[2] * xs[2];
+    const double qt = xt[0] * xt[0] + xt[1] * xt[1] + xt[2] * xt[2];
+    if (qs > bs) {
+      bs = qs;
+      ns[0] = xs[0]; ns[1] = xs[1]; ns[2] = xs[2];
+    }
+    if (qt > bt) {
+      bt = qt;
+      nt[0] = xt[0]; nt[1] = xt[1]; nt[2] = xt[2];
+    }
+  }
+  // |cross| = s1 s2 |sin|: rank <= 1 (or a second singular value below 1e-6 of the first) is left to the SVD
+  if (!(bs > 1e-24 * f2 * f2) || !(bt > 1e-24 * f2 * f2)) return false;
+  const double is = 1.0 / sqrt(bs), it = 1.0 / sqrt(bt), sigma = sqrt(f2);
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) Hc[r * 3 + c] = H[r * 3 + c] + sigma * (ns[r] * is) * (nt[c] * it);
+  if (!(det3(Hc) > 0.0)) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Hc[r * 3 + c] = H[r * 3 + c] - sigma * (ns[r] * is) * (nt[c] * it);
+  }
+  return true;
+}
+
 // R = V U' through the SVD, with the reflection fix of transformation_estimation_svd.hpp:156-160.
 // work: 42 doubles (see svd3).
 PCLMI_HD void svd_rotation(const double H[9], double R[9], double *work) {
@@ -238,7 +289,10 @@ PCLMI_HD bool solve_from_sums(const double *sums, float T[16], double *work /* 4
 #pragma unroll
     for (int c = 0; c < 3; ++c) H[r * 3 + c] = sums[7 + r * 3 + c] - n * ms[r] * mt[c];
   double R[9];
-  if (!polar_rotation(H, R)) svd_rotation(H, R, work);
+  if (!polar_rotation(H, R)) {
+    double Hc[9];
+    if (!(rank2_completion(H, Hc) && polar_rotation(Hc, R))) svd_rotation(H, R, work);
+  }
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     double rc = 0;

@@ -194,3 +194,88 @@ def test_c4_icp_1m_x_1m_30_iterations(capi, orc):
     a.end(want_aligned=False)
     b.end(want_aligned=False)
     assert np.abs(Tf - T).max() <= 1e-5
+
+
+def c4_clouds():
+    import bench
+    n = 1_000_000
+    tgt = bench.surface_cloud(n, SEED_T + 10)
+    T0 = bench.rigid(1.0, (1, 1, 1), (2.0, -1.0, 0.5))
+    c = np.array([512.0, 512.0, 512.0])
+    T0[:3, 3] += c - T0[:3, :3] @ c
+    rng = np.random.default_rng(SEED_Q + 10)
+    src = tgt[rng.permutation(n)] + rng.normal(0, 0.1, (n, 3)).astype(np.float32)
+    Ti = np.linalg.inv(T0)
+    src = (src.astype(np.float64) @ Ti[:3, :3].T + Ti[:3, 3]).astype(np.float32)
+    return tgt, src, T0
+
+
+def test_c4_icp_1m_x_1m_ransac_on(capi, orc):
+    # configs[3]'s clouds with the reference's DEFAULT rejection step (icp.h:104: 1000 trials, icp.hpp:113-150):
+    # the first iterations need many trials (few inliers: host-fed batches), the later ones settle with the first
+    # model inside the fused kernel.  Against the oracle's one-trial-at-a-time loop: same pairs, T within 1e-5.
+    tgt, src, T0 = c4_clouds()
+    tree = capi.Tree(tgt)
+    p, po = capi.icp_default_params(), orc.icp_default_params()
+    for x in (p, po):
+        x.max_iterations, x.max_correspondence_distance, x.ransac_iterations = 5, 25.0, 1000
+        x.ransac_outlier_threshold = 0.5
+    po.svd_scalar_double = 1
+    rc, T, out, st = capi.icp_align(tree, src, p)
+    rco, To, outo, sto = orc.icp_align(src, tgt, po, nthreads=16)
+    assert rc == 0 and rco == 0 and st.iterations == sto.iterations == 5
+    assert st.last_correspondences == sto.last_correspondences
+    assert 3 <= st.last_inliers <= st.last_correspondences
+    assert np.abs(T - To).max() <= 1e-5, np.abs(T - To).max()
+    assert np.abs(T - T0).max() < 5e-3, "five iterations with the rejection step are close to the known motion"
+    tree.close()
+
+
+def test_c4_icp_1m_x_1m_point_to_plane(capi, orc):
+    # configs[3]'s clouds with TransformationEstimationPointToPlaneLLS in the loop (registration.h:140-160), target
+    # normals from the fused k = 16 normal estimation; 10 iterations against the oracle's loop
+    tgt, src, T0 = c4_clouds()
+    tree = capi.Tree(tgt)
+    tn = capi.normals(tree, tgt, k=16, viewpoint=(512.0, 512.0, 5000.0))[:, :3].copy()
+    p, po = capi.icp_default_params(), orc.icp_default_params()
+    for x in (p, po):
+        x.max_iterations, x.max_correspondence_distance, x.ransac_iterations = 10, 25.0, 0
+    rc, T, out, st = capi.icp_align_point_to_plane(tree, src, tn, p)
+    rco, To, outo, sto = orc.icp_align_point_to_plane(src, tgt, tn, po, nthreads=16)
+    assert rc == 0 and rco == 0 and st.iterations == sto.iterations == 10
+    assert st.last_correspondences == sto.last_correspondences
+    assert np.abs(T - To).max() <= 1e-5, np.abs(T - To).max()
+    # how far BOTH end from the motion the source was made with: the linearised point-to-plane estimator on a cloud of
+    # 64 planes leaves the in-plane components weakly determined (bench.py reports the same figure for the GPU loop)
+    assert abs(np.abs(T - T0).max() - np.abs(To - T0).max()) <= 2e-5
+    tree.close()
+
+
+@pytest.mark.parametrize("n", [30_000, 1_000_000])
+def test_fp32_reference_estimator_is_within_its_accumulation_bound(capi, orc, n):
+    # The 1e-5 bar is held against the reference's estimator instantiated with Scalar = double
+    # (transformation_estimation_svd.h:57); its DEFAULT instantiation accumulates centroids and H in fp32
+    # (centroid.hpp:48-75, transformation_estimation_svd.hpp:114-134).  One iteration from the same pairs: the GPU's
+    # fp64 result and the oracle's fp32-estimator result differ by no more than the rounding of sequential fp32 sums -
+    # a random walk of n additions, each rounding a partial sum of up to n M / 2 to 2^-24 relative:
+    #   |error of a mean| <~ c sqrt(n) 2^-24 M     (M = coordinate magnitude; c = 4 leaves room for the tail)
+    # and the rotation's entries by the same figure relative to the cloud's extent.
+    tgt, src, T0 = c4_clouds()
+    sel = np.random.default_rng(11).choice(len(src), n, replace=False)
+    src = np.ascontiguousarray(src[sel])
+    tree = capi.Tree(tgt)
+    p, po32, po64 = capi.icp_default_params(), orc.icp_default_params(), orc.icp_default_params()
+    for x in (p, po32, po64):
+        x.max_iterations, x.max_correspondence_distance, x.ransac_iterations = 1, 25.0, 0
+    po64.svd_scalar_double = 1
+    rc, T, _, st = capi.icp_align(tree, src, p)
+    _, T32, _, st32 = orc.icp_align(src, tgt, po32, nthreads=16)
+    _, T64, _, st64 = orc.icp_align(src, tgt, po64, nthreads=16)
+    assert rc == 0 and st.last_correspondences == st32.last_correspondences == st64.last_correspondences
+    assert np.abs(T - T64).max() <= 1e-5
+    M, extent, u = 1024.0, 1024.0, 2.0 ** -24
+    bound_t = 4 * np.sqrt(n) * u * M
+    bound_r = bound_t / extent * 4  # H's entries are sums of products of demeaned coordinates: same walk, twice
+    assert np.abs(T[:3, 3] - T32[:3, 3]).max() <= bound_t, (np.abs(T[:3, 3] - T32[:3, 3]).max(), bound_t)
+    assert np.abs(T[:3, :3] - T32[:3, :3]).max() <= bound_r, (np.abs(T[:3, :3] - T32[:3, :3]).max(), bound_r)
+    tree.close()
