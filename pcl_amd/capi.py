@@ -74,6 +74,8 @@ SIGNATURES = {
                                 C.c_void_p]),
     "pclmi_knn_dev_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p,
                                       C.c_void_p]),
+    "pclmi_knn_dev_pipelined": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p,
+                                          C.c_void_p, C.c_void_p]),
     "pclmi_knn_dev_noalloc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p,
                                         C.c_void_p, C.c_void_p]),
     "pclmi_knn_kernel_name": (C.c_char_p, [C.c_void_p, C.c_size_t, C.c_int]),
@@ -319,6 +321,10 @@ class Tree:
     def knn_dev_async(self, q_ptr, nq, q_stride_bytes, k, idx_ptr, d2_ptr, stream=None):
         """As knn_dev, but only enqueues on `stream` (pclmi_knn_dev_async)."""
         _check(load_library().pclmi_knn_dev_async(self.h, q_ptr, nq, q_stride_bytes, k, idx_ptr, d2_ptr, stream))
+
+    def knn_dev_pipelined(self, q_ptr, nq, q_stride_bytes, k, idx_ptr, d2_ptr, stream=None):
+        """pclmi_knn_dev_pipelined: queries already valid at call time; the ordering pass overlaps the previous call."""
+        _check(load_library().pclmi_knn_dev_pipelined(self.h, q_ptr, nq, q_stride_bytes, k, idx_ptr, d2_ptr, stream))
 
     def knn_dev_noalloc(self, q_ptr, nq, q_stride_bytes, k, idx_ptr, d2_ptr, stream=None):
         """pclmi_knn_dev_noalloc: enqueue-only, scratch in the library's static device array (no hipMalloc)."""

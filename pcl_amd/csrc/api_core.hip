@@ -229,6 +229,8 @@ int Workspace::ensure_buf(int which, size_t bytes) {
 void Workspace::release() {
   if (ev) (void)hipEventDestroy(ev);
   ev = nullptr;
+  if (ev_order) (void)hipEventDestroy(ev_order);
+  ev_order = nullptr;
   if (fixed) {  // nothing here is ours
     *this = Workspace();
     return;
@@ -587,6 +589,7 @@ void pclmi_tree_destroy(pclmi_tree *t) {
   if (t->d_slot) (void)hipFree(t->d_slot);
   if (t->d_cloud) (void)hipFree(t->d_cloud);
   if (t->stream) (void)hipStreamDestroy(t->stream);
+  if (t->side) (void)hipStreamDestroy(t->side);
   delete t;
 }
 
@@ -621,6 +624,66 @@ int pclmi_knn_dev_async(const pclmi_tree *t, const float *d_q, size_t nq, size_t
   Workspace *w = acquire_ws(t, s);
   const int rc = knn_enqueue(t, w, d_q, nq, q_stride_bytes, k_eff, d_idx, d_d2, s);
   release_ws_async(t, w, s);  // the next user of w is ordered behind this call's kernels by an event, not the host
+  return rc;
+}
+
+// The ordering pass (four short, latency-bound kernels: 8 % of a 1M-query k = 16 call) of call i + 1 on the tree's side
+// stream, under the traversal of call i; the traversal waits for its ordering pass through an event.  The workspaces of
+// consecutive calls alternate (a workspace is reused once the traversal that read it has finished).
+int pclmi_knn_dev_pipelined(const pclmi_tree *t, const float *d_q, size_t nq, size_t q_stride_bytes, int k,
+                            int32_t *d_idx, float *d_d2, void *stream) {
+  int k_eff = 0;
+  RC(knn_check(t, d_q, nq, q_stride_bytes, k, d_idx, d_d2, &k_eff));
+  if (nq == 0 || k_eff == 0) return PCLMI_OK;
+  PCLMI_HIP(hipSetDevice(t->device));
+  hipStream_t s = stream ? (hipStream_t)stream : t->stream;
+  Workspace *w = nullptr;
+  hipStream_t side = nullptr;
+  {
+    std::lock_guard<std::mutex> g(t->mu);
+    if (!t->side) {
+      // lowest priority: the pass has a whole traversal's time to finish; its waves should take the slots the
+      // traversal leaves, not compete for them
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+      if (hipStreamCreateWithPriority(&t->side, hipStreamNonBlocking, lo) != hipSuccess) {
+        t->side = nullptr;
+        return hip_fail(hipGetLastError(), "hipStreamCreate (side stream)", __FILE__, __LINE__);
+      }
+    }
+    side = t->side;
+    for (size_t i = 0; i < t->pool.size(); ++i) {
+      Workspace *c = t->pool[i];
+      if (!c->in_flight || (c->ev && hipEventQuery(c->ev) == hipSuccess)) {
+        w = c;
+        w->in_flight = false;
+        t->pool.erase(t->pool.begin() + (long)i);
+        break;
+      }
+    }
+    if (!w && (t->pool.empty() || t->n_pipe_ws < 3)) {
+      w = new Workspace();
+      ++t->n_pipe_ws;
+    }
+    if (!w) {  // every workspace is still being read: the oldest one, behind its traversal
+      w = t->pool.front();
+      t->pool.erase(t->pool.begin());
+    }
+  }
+  (void)hipGetLastError();  // hipEventQuery's hipErrorNotReady is not an error
+  if (w->in_flight && w->ev) PCLMI_HIP(hipStreamWaitEvent(side, w->ev, 0));
+  const int32_t *order = nullptr;
+  int rc = launch_morton_order(t, w, d_q, nq, q_stride_bytes / 4, nullptr, nullptr, side, &order);
+  if (!rc && order) {
+    if (!w->ev_order && hipEventCreateWithFlags(&w->ev_order, hipEventDisableTiming) != hipSuccess) w->ev_order = nullptr;
+    if (w->ev_order && hipEventRecord(w->ev_order, side) == hipSuccess) {
+      if (hipStreamWaitEvent(s, w->ev_order, 0) != hipSuccess) rc = hip_fail(hipGetLastError(), "hipStreamWaitEvent", __FILE__, __LINE__);
+    } else {
+      (void)hipStreamSynchronize(side);  // no event: wait here
+    }
+  }
+  if (!rc) rc = launch_knn(t, w, d_q, nq, q_stride_bytes / 4, order, k_eff, d_idx, d_d2, s);
+  release_ws_async(t, w, s);
   return rc;
 }
 

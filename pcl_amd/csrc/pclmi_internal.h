@@ -112,6 +112,9 @@ struct pclmi_tree {
   mutable std::mutex mu;
   mutable std::vector<pclmi::Workspace *> pool;
   mutable std::vector<pclmi::HostSlot *> host_pool;
+  // pclmi_knn_dev_pipelined: the ordering pass of a call runs on this stream, under the previous call's traversal
+  mutable hipStream_t side = nullptr;
+  mutable int n_pipe_ws = 0;  // workspaces created for pipelined calls (a few alternate)
 
   pclmi::TreeView view() const { return pclmi::TreeView{d_box, d_leaf, d_cloud, d_slot, M, (int)n}; }
 };
@@ -138,6 +141,7 @@ struct Workspace {
   // stream-ordered reuse (pclmi_knn_dev_async): `ev` is recorded on `last` when the workspace goes back to the pool
   // with work still queued; the next user on another stream waits for it on its stream, not on the host
   hipEvent_t ev = nullptr;
+  hipEvent_t ev_order = nullptr;  // pipelined calls: the ordering pass on the side stream has finished
   hipStream_t last = nullptr;
   bool in_flight = false;
   int ensure_queries(size_t nq, size_t nbins);
