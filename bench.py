@@ -566,48 +566,66 @@ def bench_extras(env, tree, target, q_host, q_dev, stream):
     build10 = time.time() - t0
     lo, hi = sweep.rank_slice(100_000_000, rank if world <= 8 else rank % 8, 8)
     share = hi - lo
-    qs = torch.from_numpy(uniform_cloud(share, SEED_Q + 100 + rank, 0, 2048)).pin_memory()
+    # TWO consecutive shares of the sweep (25M queries): the batch is one share (sweep.DEFAULT_BATCH = 12.5M - as dense
+    # as the target, see pcl_amd/sweep.py), so the upload of the second overlaps the search of the first
+    n_sw = 2 * share
+    qs = torch.from_numpy(uniform_cloud(n_sw, SEED_Q + 100 + rank, 0, 2048)).pin_memory()
     k32 = 32
-    oi = torch.empty((share, k32), dtype=torch.int32, device=dev)
-    od = torch.empty((share, k32), dtype=torch.float32, device=dev)
-    log("extras: configs[4] sweep (%d queries in 4M batches)" % share)
-    sweep.knn_sweep(tree10, qs, k32, batch=4_000_000, device=dev, out=(oi, od))  # warm-up
+    oi = torch.empty((n_sw, k32), dtype=torch.int32, device=dev)
+    od = torch.empty((n_sw, k32), dtype=torch.float32, device=dev)
+    log("extras: configs[4] sweep (%d queries in batches of %d)" % (n_sw, share))
+    sweep.knn_sweep(tree10, qs, k32, batch=share, device=dev, out=(oi, od))  # warm-up
     capi.timing_enable(2 << capi.TIMER_KNN)
     capi.timing_read(capi.TIMER_KNN, reset=True)
     barrier()
     tm = {}
     t0 = time.perf_counter()
-    sweep.knn_sweep(tree10, qs, k32, batch=4_000_000, device=dev, out=(oi, od), timings=tm)
+    sweep.knn_sweep(tree10, qs, k32, batch=share, device=dev, out=(oi, od), timings=tm)
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
     s_ms, s_n = capi.timing_read(capi.TIMER_KNN, reset=True)
-    # the same share uploaded in the same 4M batches but searched in ONE call (all its queries ordered together)
-    sweep.knn_sweep(tree10, qs, k32, batch=4_000_000, device=dev, out=(oi, od), resident=True)
+    # one share alone, uploaded and searched in ONE call (nothing to overlap the upload with)
+    one = (oi[:share], od[:share])
+    sweep.knn_sweep(tree10, qs[:share], k32, batch=share, device=dev, out=one, resident=True)
     capi.timing_read(capi.TIMER_KNN, reset=True)
     barrier()
     t0 = time.perf_counter()
-    sweep.knn_sweep(tree10, qs, k32, batch=4_000_000, device=dev, out=(oi, od), resident=True)
+    sweep.knn_sweep(tree10, qs[:share], k32, batch=share, device=dev, out=one, resident=True)
     barrier()
     dt_res = max_over_ranks(time.perf_counter() - t0)
     res_ms, res_n = capi.timing_read(capi.TIMER_KNN, reset=True)
+    # round 2's batch size for the record: the same share in 4M batches (0.4 queries per target point)
+    sweep.knn_sweep(tree10, qs[:share], k32, batch=4_000_000, device=dev, out=one)
+    capi.timing_read(capi.TIMER_KNN, reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    sweep.knn_sweep(tree10, qs[:share], k32, batch=4_000_000, device=dev, out=one)
+    barrier()
+    dt_4m = max_over_ranks(time.perf_counter() - t0)
+    b4_ms, b4_n = capi.timing_read(capi.TIMER_KNN, reset=True)
     capi.timing_enable(False)
-    s_algo = share * (16 + 8 * k32) + 16 * 10_000_000
-    ex["knn32_10m"] = {"workload": "configs[4]: 10M-point target, one GPU's share (%d of 100M queries), k = 32, queries "
-                                   "uploaded in 4M batches overlapped with the search, results kept in HBM" % share,
-                       "value": world * share / dt, "unit": "queries/s", "seconds_per_share": dt,
+    s_algo = n_sw * (16 + 8 * k32) + 2 * 16 * 10_000_000  # two launches, each touches the target once
+    pmc32, pmc32_from = pmc_summary("knn32")
+    ex["knn32_10m"] = {"workload": "configs[4]: 10M-point target, two consecutive shares of one GPU (%d of 100M queries "
+                                   "each), k = 32, one share per batch: upload of the second overlapped with the search "
+                                   "of the first, results kept in HBM" % share,
+                       "value": world * n_sw / dt, "unit": "queries/s", "seconds_per_share": dt / 2,
                        "tree_build_s": round(build10, 3),
                        "one_search_over_the_share": {"value": world * share / dt_res, "unit": "queries/s",
                                                      "seconds_per_share": dt_res, "kernel_ms": res_ms,
                                                      "launches": int(res_n),
-                                                     "frac": s_algo / (res_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if res_ms else None,
-                                                     "note": "same uploads, one pclmi_knn_dev_async over all 12.5M "
-                                                             "queries (sweep.knn_sweep resident=True)"},
-                       "roofline": {"bound": "hbm", "kernel": tree10.knn_kernel_name(k32, 4_000_000),
+                                                     "note": "one share alone: upload, then one "
+                                                             "pclmi_knn_dev_async (sweep.knn_sweep resident=True)"},
+                       "batches_of_4m": {"value": world * share / dt_4m, "unit": "queries/s", "kernel_ms": b4_ms,
+                                         "launches": int(b4_n),
+                                         "note": "round 2's batch size: every batch 0.4 queries per target point"},
+                       "roofline": {"bound": "hbm", "kernel": tree10.knn_kernel_name(k32, share),
                                     "kernel_ms": s_ms, "launches": int(s_n), "algorithmic_bytes": s_algo,
-                                    "bytes_per_query": s_algo / share,
+                                    "bytes_per_query": s_algo / n_sw,
                                     "achieved": s_algo / (s_ms * 1e-3) / 1e9 if s_ms else None, "peak": HBM_PEAK_GBS,
                                     "unit": "GB/s", "frac": s_algo / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if s_ms else None,
-                                    "traffic": None}}
+                                    "kernel_queries_per_s": n_sw / (s_ms * 1e-3) if s_ms else None,
+                                    "traffic": pmc_traffic(pmc32), "traffic_from": pmc32_from}}
     del oi, od, qs
     tree10.close()
     if rank == 0:

@@ -34,8 +34,10 @@
 #ifndef PCLMI_IX16
 #define PCLMI_IX16 40
 #endif
+// (round 3: 48 entries = 12 KB per wave = three waves per SIMD instead of two with 80; 1M x 1M, k = 32: 1.047 -> 0.962 ms,
+//  12.5M queries on the 10M-point target 12.42 -> 10.83 ms; 44 / 52 entries and four waves with 40: slower)
 #ifndef PCLMI_IX32
-#define PCLMI_IX32 80
+#define PCLMI_IX32 48
 #endif
 // keep the pre-pass list (see knn_union_ix_kernel); 0 = round-1 behaviour, for A/B runs
 #ifndef PCLMI_RETAIN
@@ -353,7 +355,7 @@ __device__ __forceinline__ void normals_finish(unsigned int (*buf)[64], const fl
 #define PCLMI_WAVES16 4
 #endif
 #ifndef PCLMI_WAVES32
-#define PCLMI_WAVES32 2
+#define PCLMI_WAVES32 3
 #endif
 template <int K, int C, int WPB, bool NRM = false>
 __global__ __launch_bounds__(64 * WPB)

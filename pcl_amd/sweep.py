@@ -1,11 +1,17 @@
 """Streamed k-NN sweep: BASELINE configs[4] (100M queries, k = 32, against a 10M-point target) as a workload.
 
 The batched form of the reference's per-point loop (search/include/pcl/search/search.h:244-262) at a size where the
-queries do not arrive in one piece: a rank's share of the queries (12.5M of the 100M on 8 GPUs) is uploaded in
-batches (4M by default) on a copy stream while the previous batch is searched on the compute stream
-(pclmi_knn_dev_async: enqueue-only, the workspace changes hands in stream order); the neighbour lists stay in HBM
-(12.5M x 32 x 8 B = 3.2 GB).  Queries shard over ranks with no collective.  torch is plumbing: pinned host memory,
-device buffers, streams and events.
+queries do not arrive in one piece: a rank's queries are uploaded in batches on a copy stream while the previous
+batch is searched on the compute stream (pclmi_knn_dev_async: enqueue-only, the workspace changes hands in stream
+order); the neighbour lists stay in HBM.  Queries shard over ranks with no collective.  torch is plumbing: pinned host
+memory, device buffers, streams and events.
+
+Batch size (round 3).  What a wavefront of the traversal costs is the union of its 64 queries' search balls, so a batch
+should be as DENSE as the target: a 4M batch on the 10M-point target is 0.4 queries per target point and costs 45 %
+more kernel time per query than 12.5M queries searched together (measured: 18.1 ms in four launches against 12.5 ms in
+one).  HBM is 288 GB - a 12.5M-query batch is 200 MB of queries and 3.2 GB of results - so the default batch is
+DEFAULT_BATCH = 12.5M queries (one GPU's share of the 100M on 8 GPUs): the upload of batch i + 1 still overlaps the
+search of batch i, and every batch is searched at full density.
 """
 import numpy as np
 
@@ -17,7 +23,10 @@ def rank_slice(n_total, rank, world):
     return lo, min(n_total, lo + per)
 
 
-def knn_sweep(tree, queries, k, batch=4_000_000, device=None, out=None, timings=None, resident=False):
+DEFAULT_BATCH = 12_500_000
+
+
+def knn_sweep(tree, queries, k, batch=DEFAULT_BATCH, device=None, out=None, timings=None, resident=False):
     """queries: (n, 3 | 4) float32 host array (numpy, or a pinned torch tensor).  Returns (idx, d2) CUDA tensors
     [n, k_eff] resident in HBM.  timings (dict, optional) receives the wall time of the pipeline in seconds.
 
