@@ -113,6 +113,7 @@ struct pclmi_tree {
   mutable std::vector<pclmi::Workspace *> pool;
   mutable std::vector<pclmi::HostSlot *> host_pool;
   // pclmi_knn_dev_pipelined: the ordering pass of a call runs on this stream, under the previous call's traversal
+  mutable double radius_hint = 0.0;  // neighbours per query of the last radius search (sizes the next call's output)
   mutable hipStream_t side = nullptr;
   mutable int n_pipe_ws = 0;  // workspaces created for pipelined calls (a few alternate)
 

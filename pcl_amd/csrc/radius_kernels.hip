@@ -474,11 +474,18 @@ __global__ __launch_bounds__(64 * SORT64_WPB) void segment_sort64_kernel(u64 *__
 // Two consecutive segments of at most 32 keys each (most of them, at ~31 neighbours per query) share one pass of
 // the 32-key network: the first in lanes 0-31, the second in lanes 32-63 - the network's last stage leaves the
 // upper half in DESCENDING order, so its lanes write mirrored.
+// (Measured and dropped, round 3: rows of 4-byte bucket slots with the keys recomputed here from the slot's row -
+//  half the provisional bytes, traversal 384 -> 365 us, but this kernel 212 -> 298 us: it is bound by issue slots
+//  and the 31M row gathers cost more than the bytes they save.)
 __global__ __launch_bounds__(64 * SORT64_WPB) void prov_sort_kernel(const u64 *__restrict__ prov,
                                                                      const unsigned int *__restrict__ counts,
                                                                      const u64 *__restrict__ offsets, int nq,
                                                                      int by_index, int *__restrict__ idx_out,
-                                                                     float *__restrict__ d2_out) {
+                                                                     float *__restrict__ d2_out,
+                                                                     const unsigned int *__restrict__ n_over, u64 cap) {
+  // (enqueued before the host knows the totals: nothing to do here when a query overflowed its row or the output
+  //  arrays - sized from the previous call - are too small; the host then takes the other path)
+  if (*n_over != 0u || offsets[nq] > cap) return;
   const int lane = threadIdx.x & 63;
   const int half = lane >> 5, l32 = lane & 31;
   const int seg0 = (blockIdx.x * SORT64_WPB + (threadIdx.x >> 6)) * SORT64_SEGS;
@@ -762,14 +769,62 @@ int radius_search_dev(const pclmi_tree *t, Workspace *w, const float *d_q, size_
   if (rc) return rc;
   u64 total = 0;
   unsigned int n_over = 0;
-  PCLMI_HIP(hipMemcpyAsync(&total, d_off_full + nq, sizeof(u64), hipMemcpyDeviceToHost, s));
-  PCLMI_HIP(hipMemcpyAsync(&n_over, d_nover, sizeof(n_over), hipMemcpyDeviceToHost, s));
-  PCLMI_HIP(hipStreamSynchronize(s));
+  auto launch_prov_sort = [&](int32_t *pi, float *pd, u64 cap) {
+    hipLaunchKernelGGL(prov_sort_kernel,
+                       dim3((unsigned)((nq + SORT64_WPB * SORT64_SEGS - 1) / (SORT64_WPB * SORT64_SEGS))),
+                       dim3(64 * SORT64_WPB), 0, s, (const u64 *)prov, (const unsigned int *)d_counts,
+                       (const u64 *)d_off_full, (int)nq, by_index, pi, pd, (const unsigned int *)d_nover, cap);
+  };
+  // The output arrays are sized from the totals, which only the device knows at this point.  A tree remembers the
+  // neighbours per query of its last radius search: with that estimate (+ 25 %) the arrays are allocated and the
+  // sort is enqueued BEFORE the totals are read back - one host synchronisation per call instead of two; when the
+  // estimate was too small (or a query overflowed its row) the sort does nothing and the exact path below runs.
+  int32_t *spi = nullptr;
+  float *spd = nullptr;
+  u64 spec_cap = 0;
+  if (try_prov && t->radius_hint > 0.0 && (double)nq * t->radius_hint < (double)((u64)1 << 28)) {
+    spec_cap = (u64)((double)nq * t->radius_hint * 1.25) + 4096;
+    spi = (int32_t *)dev_cache_get(spec_cap * sizeof(int32_t));
+    spd = (float *)dev_cache_get(spec_cap * sizeof(float));
+    if (spi && spd) {
+      launch_prov_sort(spi, spd, spec_cap);
+    } else {
+      dev_cache_put(spi);
+      dev_cache_put(spd);
+      spi = nullptr;
+      spd = nullptr;
+      spec_cap = 0;
+    }
+  }
+  auto drop_spec = [&]() {
+    dev_cache_put(spi);
+    dev_cache_put(spd);
+    spi = nullptr;
+    spd = nullptr;
+  };
+  {
+    hipError_t e1 = hipMemcpyAsync(&total, d_off_full + nq, sizeof(u64), hipMemcpyDeviceToHost, s);
+    if (e1 == hipSuccess) e1 = hipMemcpyAsync(&n_over, d_nover, sizeof(n_over), hipMemcpyDeviceToHost, s);
+    if (e1 == hipSuccess) e1 = hipStreamSynchronize(s);
+    if (e1 != hipSuccess) {
+      drop_spec();
+      return hip_fail(e1, "radius search", __FILE__, __LINE__);
+    }
+  }
+  t->radius_hint = nq ? (double)total / (double)nq : 0.0;
   if (total == 0) {
+    drop_spec();
     if (max_nn) PCLMI_HIP(hipMemsetAsync(d_offsets, 0, (nq + 1) * sizeof(uint64_t), s));
     PCLMI_HIP(hipStreamSynchronize(s));
     return PCLMI_OK;
   }
+  if (spi && n_over == 0 && total <= spec_cap) {  // the enqueued sort has done it
+    *d_idx = spi;
+    *d_d2 = spd;
+    *total_out = total;
+    return PCLMI_OK;
+  }
+  drop_spec();
   if (try_prov && n_over == 0) {
     int32_t *pi = (int32_t *)dev_cache_get(total * sizeof(int32_t));
     float *pd = (float *)dev_cache_get(total * sizeof(float));
@@ -778,10 +833,7 @@ int radius_search_dev(const pclmi_tree *t, Workspace *w, const float *d_q, size_
       dev_cache_put(pd);
       return PCLMI_ERR_OOM;
     }
-    hipLaunchKernelGGL(prov_sort_kernel,
-                       dim3((unsigned)((nq + SORT64_WPB * SORT64_SEGS - 1) / (SORT64_WPB * SORT64_SEGS))),
-                       dim3(64 * SORT64_WPB), 0, s, (const u64 *)prov, (const unsigned int *)d_counts,
-                       (const u64 *)d_off_full, (int)nq, by_index, pi, pd);
+    launch_prov_sort(pi, pd, total);
     hipError_t pe = hipGetLastError();
     if (pe == hipSuccess) pe = hipStreamSynchronize(s);
     if (pe != hipSuccess) {
