@@ -182,7 +182,7 @@ __device__ __forceinline__ int compact_index_buffer(unsigned int (*buf)[64], con
 template <int K, int C>
 __device__ __forceinline__ void knn_finish(unsigned int (*buf)[64], const float4 *__restrict__ cloud, const LaneQuery &lq,
                                            int lane, int cnt, float tau, int k_out, int *__restrict__ out_idx,
-                                           float *__restrict__ out_d2) {
+                                           float *__restrict__ out_d2, int pitch) {
   const float qx = lq.x, qy = lq.y, qz = lq.z;
   unsigned long long key[K];
   if constexpr (PCLMI_FINISH_ONE_GATHER && K >= PCLMI_ONE_GATHER_MIN_K && C / 2 >= K) {
@@ -244,11 +244,11 @@ __device__ __forceinline__ void knn_finish(unsigned int (*buf)[64], const float4
   }
   sort_keys<K>(key);
   if (lq.alive) {
-    int *oi = out_idx + (size_t)lq.qi * k_out;
-    float *od = out_d2 + (size_t)lq.qi * k_out;
+    int *oi = out_idx + (size_t)lq.qi * pitch;
+    float *od = out_d2 + (size_t)lq.qi * pitch;
     // full rows on 16-byte boundaries (the usual case): 128-bit stores - a 4-byte store per neighbour makes every
     // store instruction touch 64 different cache lines
-    const bool wide = K % 4 == 0 && k_out == K &&
+    const bool wide = K % 4 == 0 && k_out == K && pitch % 4 == 0 &&
                       ((((unsigned long long)out_idx | (unsigned long long)out_d2) & 15ull) == 0ull);
     if (wide) {
 #pragma unroll
@@ -357,14 +357,18 @@ __device__ __forceinline__ void normals_finish(unsigned int (*buf)[64], const fl
 #ifndef PCLMI_WAVES32
 #define PCLMI_WAVES32 3
 #endif
-template <int K, int C, int WPB, bool NRM = false>
+// LOW (k > 64, see launch_knn): one TILE of a long neighbour list - the K nearest among the points whose (d2, index)
+// key lies ABOVE the last key of the previous tile, which the previous launch left at out[qi * pitch - 1] (out_idx /
+// out_d2 point at the tile's first column; pitch = the row length of the whole list).
+template <int K, int C, int WPB, bool NRM = false, bool LOW = false>
 __global__ __launch_bounds__(64 * WPB)
     __attribute__((amdgpu_waves_per_eu(K == 16 ? PCLMI_WAVES16 : K <= 4 ? 7 : K == 8 ? 6 : K == 32 ? PCLMI_WAVES32 : 1))) void knn_union_ix_kernel(TreeView t, const float *__restrict__ q,
                                                                  int q_stride_f, const int *__restrict__ order,
                                                                  int nq, int k_out, int *__restrict__ out_idx,
                                                                  float *__restrict__ out_d2, float vpx, float vpy,
-                                                                 float vpz, int qpw) {
+                                                                 float vpz, int qpw, int pitch) {
   static_assert(C >= K + 8, "buffer must hold the K best plus two groups of appends");
+  static_assert(!(LOW && NRM), "tiles are neighbour lists");
   __shared__ unsigned int lds[WPB][C][64];
   const int lane = threadIdx.x & 63;
   LaneQuery lq;
@@ -381,13 +385,23 @@ __global__ __launch_bounds__(64 * WPB)
   // candidate instead of after K of them.  When the walk reaches a home bucket the lane appends what is still within
   // its bound but inserts nothing (those distances are in a[] already).
   int home = -0x40000000;  // no bucket number is near it: lanes without a query have no home
+  float lo_d = -1.f;        // LOW: the previous tile's last key; only keys above it count
+  unsigned int lo_i = 0u;
   if (lq.searchable) {
+    if constexpr (LOW) {
+      // no pre-pass: its list would have to leave out the points of the earlier tiles; the walk starts unbounded
+      lo_d = out_d2[(size_t)lq.qi * pitch - 1];
+      lo_i = (unsigned int)out_idx[(size_t)lq.qi * pitch - 1];
+#pragma unroll
+      for (int j = 0; j < K; ++j) a[j] = 3.402823466e+38f;
+    } else {
 #if PCLMI_NOPREPASS
 #pragma unroll
     for (int j = 0; j < K; ++j) a[j] = 3.402823466e+38f;
 #else
     lane_bound_list<K>(t, qx, qy, qz, a, home);
 #endif
+    }
   } else {
 #pragma unroll
     for (int j = 0; j < K; ++j) a[j] = -1.f;
@@ -468,7 +482,13 @@ __global__ __launch_bounds__(64 * WPB)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float d = dd[j];
-          const bool pass = d <= a[K - 1];
+          bool pass = d <= a[K - 1];
+          bool above = true;
+          if constexpr (LOW) {
+            const unsigned int ib = __float_as_uint(grp[g][12 + j]);
+            above = d > lo_d || (d == lo_d && ib > lo_i);
+            pass = pass && above;
+          }
 #if PCLMI_RETAIN
           const unsigned long long pb = __ballot(pass);
           if (pb) {
@@ -479,7 +499,7 @@ __global__ __launch_bounds__(64 * WPB)
             }
             if (pb & ~homeb) {  // some lane meets this point for the first time
               PCLMI_STAT(2, 1);
-              list_insert<K>(a, is_home ? __builtin_inff() : d);
+              list_insert<K>(a, (is_home || !above) ? __builtin_inff() : d);
             }
           }
 #else
@@ -507,7 +527,7 @@ __global__ __launch_bounds__(64 * WPB)
   if constexpr (NRM)
     normals_finish<K, C>(buf, cloud, lq, lane, cnt, a[K - 1], k_out, vpx, vpy, vpz, reinterpret_cast<float4 *>(out_d2));
   else
-    knn_finish<K, C>(buf, cloud, lq, lane, cnt, a[K - 1], k_out, out_idx, out_d2);
+    knn_finish<K, C>(buf, cloud, lq, lane, cnt, a[K - 1], k_out, out_idx, out_d2, pitch);
 #ifdef PCLMI_STATS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   PCLMI_TICK(tick3);
@@ -586,7 +606,7 @@ __global__ __launch_bounds__(64) void knn_lane_ix_kernel(TreeView t, const float
   if constexpr (NRM)
     normals_finish<K, C>(buf, cloud, lq, lane, cnt, a[K - 1], k_out, vpx, vpy, vpz, reinterpret_cast<float4 *>(out_d2));
   else
-    knn_finish<K, C>(buf, cloud, lq, lane, cnt, a[K - 1], k_out, out_idx, out_d2);
+    knn_finish<K, C>(buf, cloud, lq, lane, cnt, a[K - 1], k_out, out_idx, out_d2, k_out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1106,10 +1126,34 @@ static int launch_union_ix(const pclmi_tree *t, Workspace *, const float *d_q, s
   blocks = (blocks + 7) & ~7u;
   if (vp)
     hipLaunchKernelGGL((knn_union_ix_kernel<K, C, WPB, true>), dim3(blocks), dim3(64 * WPB), 0, s, t->view(), d_q,
-                       (int)qsf, order, (int)nq, k_eff, d_idx, d_d2, vp[0], vp[1], vp[2], qpw);
+                       (int)qsf, order, (int)nq, k_eff, d_idx, d_d2, vp[0], vp[1], vp[2], qpw, k_eff);
   else
     hipLaunchKernelGGL((knn_union_ix_kernel<K, C, WPB, false>), dim3(blocks), dim3(64 * WPB), 0, s, t->view(), d_q,
-                       (int)qsf, order, (int)nq, k_eff, d_idx, d_d2, 0.f, 0.f, 0.f, qpw);
+                       (int)qsf, order, (int)nq, k_eff, d_idx, d_d2, 0.f, 0.f, 0.f, qpw, k_eff);
+  return PCLMI_OK;
+}
+
+// k in 65 .. kTiledMaxK: the list in tiles of 64, one launch of the K = 64 instance per tile - the first as for
+// k = 64, every further one restricted to keys above the last key of the tile before it (LOW).  The reference's own
+// differential test searches with k = 512 (test/test_search.cpp:624-631); the per-lane heap kernel this replaces did
+// 2e7 queries/s at k = 128.
+static int launch_union_tiled(const pclmi_tree *t, const float *d_q, size_t nq, size_t qsf, const int32_t *order,
+                              int k_eff, int32_t *d_idx, float *d_d2, hipStream_t s) {
+  // the first tile spreads a sparse batch over the wavefront slots like k = 64 does; the further tiles run without the
+  // pre-pass, where lanes without a query would outvote the others in the walk's nearest-first order: full wavefronts
+  const int qpw0 = (nq * 6 < t->n) ? lane_queries_per_wave(nq, 1024) : 64;
+  for (int col = 0; col < k_eff; col += 64) {
+    const int cols = std::min(64, k_eff - col);
+    const int qpw = col == 0 ? qpw0 : 64;
+    const unsigned waves = (unsigned)((nq + qpw - 1) / qpw);
+    const unsigned blocks = (waves + 7) & ~7u;
+    if (col == 0)
+      hipLaunchKernelGGL((knn_union_ix_kernel<64, 128, 1, false, false>), dim3(blocks), dim3(64), 0, s, t->view(), d_q,
+                         (int)qsf, order, (int)nq, cols, d_idx, d_d2, 0.f, 0.f, 0.f, qpw, k_eff);
+    else
+      hipLaunchKernelGGL((knn_union_ix_kernel<64, 128, 1, false, true>), dim3(blocks), dim3(64), 0, s, t->view(), d_q,
+                         (int)qsf, order, (int)nq, cols, d_idx + col, d_d2 + col, 0.f, 0.f, 0.f, qpw, k_eff);
+  }
   return PCLMI_OK;
 }
 
@@ -1148,6 +1192,13 @@ static bool knn_sparse(const pclmi_tree *t, size_t nq) {
 #define PCLMI_STR2(x) #x
 #define PCLMI_STR(x) PCLMI_STR2(x)
 // the kernel launch_knn picks for a batch (the same rules, for reports: bench.py names the kernel it timed)
+constexpr int kTiledMaxK = 1024;
+static bool knn_force_heap();
+// k > 64 in tiles of 64 (launch_union_tiled) or on the per-lane heap kernel: the tiles' further launches walk for whole
+// wavefronts of 64 queries without a pre-pass, which loses on small batches, whose 64 queries are far apart (1M-point
+// target, tiles / heap: k = 128 - 4000 queries 6.5 / 4.5 ms, 10k 4.2 / 4.5, 30k 2.7 / 5.6, 1M 8.7 / 49.9;
+// k = 512 - 10k 28 / 17, 30k 16.8 / 22.2, 100k 24 / 37)
+static bool knn_tiled(size_t nq, int k_eff) { return k_eff > 64 && k_eff <= kTiledMaxK && nq >= 16384 && !knn_force_heap(); }
 const char *knn_kernel_name(const pclmi_tree *t, size_t nq, int k_eff) {
   if (k_eff <= 1) return "knn1_union_kernel<4> / knn1_lane_kernel<4>";
   if (k_eff <= 32 && knn_sparse(t, nq))
@@ -1159,6 +1210,7 @@ const char *knn_kernel_name(const pclmi_tree *t, size_t nq, int k_eff) {
   if (k_eff <= 16) return "knn_union_ix_kernel<16," PCLMI_STR(PCLMI_IX16) ",1>";
   if (k_eff <= 32) return "knn_union_ix_kernel<32," PCLMI_STR(PCLMI_IX32) ",1>";
   if (k_eff <= 64) return "knn_union_ix_kernel<64,128,1>";
+  if (knn_tiled(nq, k_eff)) return "knn_union_ix_kernel<64,128,1> x tiles of 64";
   return "knn_heap_kernel";
 }
 
@@ -1191,6 +1243,15 @@ int launch_knn_normals(const pclmi_tree *t, Workspace *w, const float *d_q, size
   if (rc) return rc;
   PCLMI_HIP(hipGetLastError());
   return PCLMI_OK;
+}
+
+// development switch PCLMI_BIGK=heap: k > 64 on the per-lane heap kernel (A/B against the tiles)
+static bool knn_force_heap() {
+  static const bool f = [] {
+    const char *e = getenv("PCLMI_BIGK");
+    return e && e[0] == 'h';
+  }();
+  return f;
 }
 
 int launch_knn(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, size_t qsf,
@@ -1249,6 +1310,8 @@ int launch_knn(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, s
     // Sparse batches too: there is no per-lane instance at this K, and against the heap kernel the union walk wins
     // at every batch size (1M-point target: 1000 queries 2.0 vs 2.4 ms, 10k 1.25 vs 2.6, 100k 0.93 vs 4.4)
     rc = launch_union_ix<64, 128, 1>(t, w, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
+  } else if (knn_tiled(nq, k_eff)) {
+    rc = launch_union_tiled(t, d_q, nq, qsf, order, k_eff, d_idx, d_d2, s);
   } else {
     size_t bytes = (size_t)k_eff * nq * sizeof(unsigned long long);
     rc = w->ensure_scratch(bytes);

@@ -289,3 +289,40 @@ def test_concurrent_const_queries_on_one_tree(capi, orc):
                 assert np.array_equal(u, v, equal_nan=True)
     oi, od = orc.Tree(pts).knn(qs[0], 16, nthreads=8)
     assert np.array_equal(got[0][0][0], oi)
+
+
+@pytest.mark.parametrize("k", [65, 128, 200, 512])
+def test_k_above_64_in_tiles_of_64(capi, orc, k):
+    """k > 64 on batches of >= 16 384 queries: the list in tiles of 64, every tile after the first restricted to the
+    (d2, index) keys above the last key of the tile before it (launch_union_tiled).  Exact ties ACROSS a tile boundary
+    are the point: an 11^3 lattice (dozens of equal distances per query), a cloud of 40-fold duplicates (equal
+    distances, ascending indices), NaN queries, k that is not a multiple of 64 - bit-exact against brute force; and the
+    same queries as a small batch (the heap kernel) must give the same rows."""
+    pts = util.grid_cloud()  # 1331 points
+    rng = np.random.default_rng(70 + k)
+    q = np.concatenate([pts, pts[:669] + np.float32(0.05), rng.random((15_000, 3), dtype=np.float32) - np.float32(0.5)])
+    q[5] = np.nan
+    assert len(q) >= 16_384
+    t = capi.Tree(pts)
+    gi, gd = t.knn(q, k)
+    good = np.isfinite(q).all(axis=1)
+    sel = np.flatnonzero(good)[::3]
+    oi, od = orc.knn_brute(pts, q[sel], k)
+    assert np.array_equal(gi[sel], oi) and np.array_equal(gd[sel].view(np.int32), od.view(np.int32))
+    assert (gi[~good] == -1).all() and np.isnan(gd[~good]).all()
+    hi, hd = t.knn(q[:2000], k)  # small batch: the per-lane heap kernel
+    ok = good[:2000]
+    assert np.array_equal(hi[ok], gi[:2000][ok]) and np.array_equal(hd[ok].view(np.int32), gd[:2000][ok].view(np.int32))
+    base = rng.random((60, 3), dtype=np.float32)
+    dup = np.repeat(base, 40, axis=0)  # 2400 points, each value 40 times: ties of 40 straddle the tile boundaries
+    qq = np.concatenate([base, rng.random((16_400, 3), dtype=np.float32)])
+    t2 = capi.Tree(dup)
+    gi, gd = t2.knn(qq, k)
+    oi, od = orc.knn_brute(dup, qq[::5], k)
+    assert np.array_equal(gi[::5], oi) and np.array_equal(gd[::5].view(np.int32), od.view(np.int32))
+    big = util.uniform_cloud(200_000, 71, 0, 100)
+    tb = capi.Tree(big)
+    qb = util.uniform_cloud(40_000, 72, 0, 100)
+    gi, gd = tb.knn(qb, k)
+    oi, od = orc.Tree(big).knn(qb[:3000], k, nthreads=16)
+    assert np.array_equal(gi[:3000], oi) and np.array_equal(gd[:3000].view(np.int32), od.view(np.int32))
