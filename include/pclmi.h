@@ -227,7 +227,11 @@ int pclmi_reject_trimmed(const pclmi_correspondence *in, size_t n, float overlap
  * by_distance == 0: the reference AS SHIPPED - its selection loop (:69-76) reads dists[i], an array that
  * optimizeInlierRatio has sorted in place (:87), so the FIRST #(sorted distances < trimmed) inputs are kept, in input
  * order, whatever their own distances; by_distance != 0: the documented intent - keep the correspondences whose OWN
- * distance is below the trimmed distance, input order kept.  Same count either way. */
+ * distance is below the trimmed distance, input order kept.  Same count either way.
+ * Caveat (parity unpinned): the reference's loop runs over dists[] after std::sort FOLLOWED BY nth_element (:64-78,
+ * :87); with several distances EQUAL to the trimmed distance libstdc++'s introselect may move the pivot, so the kept
+ * positions need not be a prefix there - which ones the reference keeps then depends on the standard library.  With
+ * distinct distances (and always in count) by_distance == 0 is the reference's result. */
 int pclmi_reject_var_trimmed(const pclmi_correspondence *in, size_t n, double min_ratio,
                              double max_ratio, double lambda, int by_distance, pclmi_correspondence *out,
                              size_t *n_out, double *trim_factor, double *trimmed_distance);

@@ -980,6 +980,20 @@ __global__ __launch_bounds__(BIN_TPB) void bin_sort_kernel(const uint2 *__restri
 }  // namespace
 
 
+// in-place exclusive sum of the workspace's first `count` histogram counters.  The temporary storage hipcub asks for
+// is checked against what the workspace holds (a size query allocates nothing): the static scratch of
+// pclmi_knn_dev_noalloc reserves a fixed slice for it, and an under-estimate would write past the device array.
+static int scan_hist(Workspace *w, int count, hipStream_t s) {
+  size_t need = 0;
+  PCLMI_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, need, w->hist, w->hist, count, s));
+  PCLMI_CHECK(need <= w->cap_tmp, w->fixed ? PCLMI_ERR_UNSUPPORTED : PCLMI_ERR_HIP,
+              "the scan of %d counters needs %zu bytes of temporary storage, the workspace holds %zu", count, need,
+              w->cap_tmp);
+  size_t tmp = w->cap_tmp;
+  PCLMI_HIP(hipcub::DeviceScan::ExclusiveSum(w->sort_tmp, tmp, w->hist, w->hist, count, s));
+  return PCLMI_OK;
+}
+
 int launch_morton_order(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq,
                         size_t q_stride_f, const float *bb_lo, const float *bb_hi, hipStream_t s,
                         const int32_t **d_order, bool stable) {
@@ -1067,8 +1081,7 @@ int launch_morton_order(const pclmi_tree *t, Workspace *w, const float *d_q, siz
                        (int)q_stride_f, (int)nq, bb_lo[0], bb_lo[1], bb_lo[2], gy ? tube_sc[0] : sc[0],
                        gy ? tube_sc[1] : sc[1], gy ? tube_sc[2] : sc[2], 30 - bits, lo_bits, nb_hi, tile_size, ntiles, gy, gz,
                        tube_p, w->keys_in, w->ranks, w->hist);
-    size_t tmp = w->cap_tmp;
-    PCLMI_HIP(hipcub::DeviceScan::ExclusiveSum(w->sort_tmp, tmp, w->hist, w->hist, nb_hi * ntiles + 1, s));
+    RC(scan_hist(w, nb_hi * ntiles + 1, s));
     hipLaunchKernelGGL(tile_scatter_kernel, dim3(grid), dim3(256), 0, s, w->keys_in, w->ranks, (int)nq, lo_bits, tile_size,
                        ntiles, w->hist, (uint2 *)w->scratch);
     hipLaunchKernelGGL(bin_sort_kernel, dim3(nb_hi), dim3(BIN_TPB), (size_t)(nb_lo + BIN_TPB) * sizeof(unsigned int), s,
@@ -1101,8 +1114,7 @@ int launch_morton_order(const pclmi_tree *t, Workspace *w, const float *d_q, siz
   PCLMI_HIP(hipMemsetAsync(w->hist, 0, nbins * sizeof(unsigned int), s));
   hipLaunchKernelGGL(cell_count_kernel, dim3(grid), dim3(256), 0, s, d_q, (int)q_stride_f, (int)nq,
                      bb_lo[0], bb_lo[1], bb_lo[2], sc[0], sc[1], sc[2], 30 - bits, w->keys_in, w->ranks, w->hist);
-  size_t tmp = w->cap_tmp;
-  PCLMI_HIP(hipcub::DeviceScan::ExclusiveSum(w->sort_tmp, tmp, w->hist, w->hist, (int)nbins, s));
+  RC(scan_hist(w, (int)nbins, s));
   hipLaunchKernelGGL(cell_scatter_kernel, dim3(grid), dim3(256), 0, s, w->keys_in, w->ranks, (int)nq, w->hist,
                      w->vals_out);
   PCLMI_HIP(hipGetLastError());

@@ -79,6 +79,32 @@ def test_rejectors_vs_oracle_random(capi, orc, n):
             assert (gf, gd) == (of, od) and np.array_equal(g, o)
 
 
+def test_var_trimmed_with_ties_at_the_trim_distance(capi, orc):
+    """Several distances EQUAL to the trimmed distance: the reference's selection runs over an array that std::sort and
+    then nth_element have permuted (_var_trimmed.hpp:64-78,87), so WHICH positions it keeps there depends on
+    libstdc++'s introselect - parity unpinned (pclmi.h).  What is pinned: the count (#sorted distances < trimmed), the
+    trim factor and distance, and - as shipped - that the kept inputs are the first `count` ones, in input order."""
+    from pcl_amd.capi import CORR_DTYPE
+    n = 1000
+    rng = np.random.default_rng(404)
+    c = np.zeros(n, CORR_DTYPE)
+    c["index_query"] = np.arange(n)
+    c["index_match"] = rng.integers(0, 500, n)
+    d = rng.random(n).astype(np.float32)
+    d[rng.choice(n, 400, replace=False)] = np.float32(0.5)  # a block of ties wherever the FRMS minimum falls near it
+    c["distance"] = d
+    for by_distance in (False, True):
+        g, gf, gd = capi.reject_var_trimmed(c, 0.05, 0.95, 0.95, by_distance)
+        o, of, od = orc.reject_var_trimmed(c, 0.05, 0.95, 0.95, by_distance)
+        assert (gf, gd) == (of, od)
+        count = int((np.sort(d) < np.float32(gd)).sum())
+        assert len(g) == len(o) == count
+        if by_distance:
+            assert np.array_equal(g, c[d < np.float32(gd)])
+        else:
+            assert np.array_equal(g, c[:count])  # a prefix, in input order
+
+
 def test_rejectors_empty(capi):
     from pcl_amd.capi import CORR_DTYPE
     e = np.zeros(0, CORR_DTYPE)

@@ -42,6 +42,25 @@ def test_noalloc_equals_knn_dev_two_calls_in_a_row():
     from oracle import pcl_oracle as orc
     oi, od = orc.Tree(pts).knn(q, 32, nthreads=4)
     assert np.array_equal(ia.cpu().numpy(), oi) and np.array_equal(da.cpu().numpy().view(np.int32), od.view(np.int32))
+    # the largest batch the static scratch takes (PCLMI_NOALLOC_MAX_QUERIES = 2^20: 131 073 tile counters, the scan's
+    # temporary storage checked against its slice of the array), then a small one again
+    nq, k = 1 << 20, 8
+    q = util.uniform_cloud(nq, 99, 0, 100)
+    dq = torch.from_numpy(q).to(dev)
+    ia = torch.full((nq, k), -3, dtype=torch.int32, device=dev)
+    da = torch.full((nq, k), -3.0, dtype=torch.float32, device=dev)
+    ib, db = torch.empty_like(ia), torch.empty_like(da)
+    torch.cuda.synchronize()
+    rc = lib.pclmi_knn_dev_noalloc(tree.h, dq.data_ptr(), nq, 12, k, ia.data_ptr(), da.data_ptr(), stream.cuda_stream)
+    assert rc == 0, lib.pclmi_last_error()
+    stream.synchronize()
+    rc = lib.pclmi_knn_dev(tree.h, dq.data_ptr(), nq, 12, k, ib.data_ptr(), db.data_ptr(), stream.cuda_stream)
+    assert rc == 0, lib.pclmi_last_error()
+    assert torch.equal(ia, ib) and torch.equal(da.view(torch.int32), db.view(torch.int32))
+    rc = lib.pclmi_knn_dev_noalloc(tree.h, dq.data_ptr(), 3000, 12, k, ia.data_ptr(), da.data_ptr(), stream.cuda_stream)
+    assert rc == 0, lib.pclmi_last_error()
+    stream.synchronize()
+    assert torch.equal(ia[:3000], ib[:3000]) and torch.equal(da[:3000].view(torch.int32), db[:3000].view(torch.int32))
     # limits: a clear error, nothing enqueued
     big = (1 << 20) + 1
     rc = lib.pclmi_knn_dev_noalloc(tree.h, dq.data_ptr(), big, 12, 4, ia.data_ptr(), da.data_ptr(), None)
