@@ -238,6 +238,68 @@ class CorrespondenceRejectorSampleConsensus : public CorrespondenceRejector {
   Matrix4f best_transformation_;
 };
 
+// correspondence_rejection_surface_normal.h / impl/_surface_normal.hpp:44-66.  The reference keeps the clouds and
+// normals in a type-erased DataContainer (initializeDataContainer<PointT, NormalT>() + templated setters); the same
+// calls are kept here, the normals are what the rejection reads.
+class CorrespondenceRejectorSurfaceNormal : public CorrespondenceRejector {
+ public:
+  CorrespondenceRejectorSurfaceNormal() : threshold_(1.0) { rejection_name_ = "CorrespondenceRejectorSurfaceNormal"; }
+  void setThreshold(double threshold) { threshold_ = threshold; }
+  double getThreshold() const { return threshold_; }
+  template <typename PointT, typename NormalT>
+  void initializeDataContainer() { initialized_ = true; }
+  template <typename PointT>
+  void setInputCloud(const typename pcl::PointCloud<PointT>::ConstPtr &) { check("setInputCloud"); }
+  template <typename PointT>
+  void setInputTarget(const typename pcl::PointCloud<PointT>::ConstPtr &) { check("setInputTarget"); }
+  template <typename PointT, typename NormalT>
+  void setInputNormals(const typename pcl::PointCloud<NormalT>::ConstPtr &normals) {
+    if (check("setInputNormals")) pack(*normals, src_normals_);
+  }
+  template <typename PointT, typename NormalT>
+  void setTargetNormals(const typename pcl::PointCloud<NormalT>::ConstPtr &normals) {
+    if (check("setTargetNormals")) pack(*normals, tgt_normals_);
+  }
+  void getRemainingCorrespondences(const pcl::Correspondences &original, pcl::Correspondences &remaining) override {
+    if (!initialized_) {  // _surface_normal.hpp:49-53
+      PCL_ERROR("DataContainer object is not initialized!\n");
+      return;
+    }
+    if (src_normals_.empty() || tgt_normals_.empty()) {
+      PCL_ERROR("[pcl::registration::%s] Normals are not set for the input and target point clouds\n",
+                rejection_name_.c_str());
+      return;
+    }
+    pcl::Correspondences tmp(original.size());
+    size_t n_out = 0;
+    const int rc = pclmi_reject_surface_normal(in(original), original.size(), src_normals_.data(),
+                                               src_normals_.size() / 3, 12, tgt_normals_.data(), tgt_normals_.size() / 3,
+                                               12, threshold_, out(tmp), &n_out);
+    finish(rc, n_out, tmp);
+    remaining.swap(tmp);
+  }
+
+ protected:
+  bool check(const char *fn) const {
+    if (!initialized_)
+      PCL_ERROR("[pcl::registration::%s::%s] Initilize the data container object by calling intializeDataContainer () "
+                "before using this function.\n", rejection_name_.c_str(), fn);
+    return initialized_;
+  }
+  template <typename CloudT>
+  static void pack(const CloudT &cloud, std::vector<float> &out) {
+    out.resize(cloud.points.size() * 3);
+    for (size_t i = 0; i < cloud.points.size(); ++i) {
+      out[3 * i + 0] = cloud.points[i].normal_x;
+      out[3 * i + 1] = cloud.points[i].normal_y;
+      out[3 * i + 2] = cloud.points[i].normal_z;
+    }
+  }
+  double threshold_;
+  bool initialized_ = false;
+  std::vector<float> src_normals_, tgt_normals_;
+};
+
 }  // namespace registration
 }  // namespace pcl
 #endif

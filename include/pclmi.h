@@ -218,6 +218,16 @@ int pclmi_reject_median(const pclmi_correspondence *in, size_t n, double factor,
  * output in that sorted order; negative matches are dropped. */
 int pclmi_reject_one_to_one(const pclmi_correspondence *in, size_t n, pclmi_correspondence *out,
                             size_t *n_out);
+/* CorrespondenceRejectorSurfaceNormal::getRemainingCorrespondences
+ * (registration/include/pcl/registration/impl/correspondence_rejection_surface_normal.hpp:44-66 with
+ * DataContainer::getCorrespondenceScoreFromNormals, correspondence_rejection.h:254-262): keep a pair iff the fp32 dot
+ * product (nx nx' + ny ny') + nz nz' of the source normal at index_query and the target normal at index_match, widened
+ * to double, is > threshold (strict; a NaN normal never passes); input order kept.  Normals: three floats at a byte
+ * stride (pcl::Normal: 32, pcl::PointNormal: 48 from &normal_x).  A pair whose index lies outside the normal arrays is
+ * dropped (the reference reads past its clouds). */
+int pclmi_reject_surface_normal(const pclmi_correspondence *in, size_t n, const float *src_normals, size_t n_src,
+                                size_t sn_stride_bytes, const float *tgt_normals, size_t n_tgt, size_t tn_stride_bytes,
+                                double threshold, pclmi_correspondence *out, size_t *n_out);
 /* _trimmed.hpp:42-58: keep the max(floor(overlap_ratio * n), min_correspondences) smallest
  * distances, sorted ascending; input returned unchanged when that is >= n. */
 int pclmi_reject_trimmed(const pclmi_correspondence *in, size_t n, float overlap_ratio,
@@ -257,6 +267,10 @@ int pclmi_reject_distance_dev(const pclmi_correspondence *d_in, size_t n, float 
                               pclmi_correspondence *d_out, size_t *n_out, void *stream);
 int pclmi_reject_median_dev(const pclmi_correspondence *d_in, size_t n, double factor, pclmi_correspondence *d_out,
                             size_t *n_out, double *median, void *stream);
+int pclmi_reject_surface_normal_dev(const pclmi_correspondence *d_in, size_t n, const float *d_src_normals, size_t n_src,
+                                    size_t sn_stride_bytes, const float *d_tgt_normals, size_t n_tgt,
+                                    size_t tn_stride_bytes, double threshold, pclmi_correspondence *d_out,
+                                    size_t *n_out, void *stream);
 int pclmi_reject_one_to_one_dev(const pclmi_correspondence *d_in, size_t n, pclmi_correspondence *d_out,
                                 size_t *n_out, void *stream);
 int pclmi_reject_trimmed_dev(const pclmi_correspondence *d_in, size_t n, float overlap_ratio,

@@ -780,6 +780,19 @@ int64_t orc_reject_distance(const orc_corr *in, int64_t n, float max_dist, orc_c
   return c;
 }
 
+/* impl/correspondence_rejection_surface_normal.hpp:44-66 + correspondence_rejection.h:254-262: keep iff the fp32 dot
+ * product of the two normals, widened to double, is > threshold */
+int64_t orc_reject_surface_normal(const orc_corr *in, int64_t n, const float *sn, int sns, const float *tn, int tns,
+                                  double threshold, orc_corr *out) {
+  int64_t c = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    const float *a = sn + (int64_t)in[i].index_query * sns, *b = tn + (int64_t)in[i].index_match * tns;
+    float dot = (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];
+    if ((double)dot > threshold) out[c++] = in[i];
+  }
+  return c;
+}
+
 static int cmp_double(const void *a, const void *b) {
   double x = *(const double *)a, y = *(const double *)b;
   return (x > y) - (x < y);

@@ -96,6 +96,8 @@ int64_t orc_correspondences(const float *src, int64_t ns, int sstride, const flo
 /* Rejectors (registration/include/pcl/registration/impl/correspondence_rejection_*.hpp).
  * All write to out (capacity n) and return the remaining count. */
 int64_t orc_reject_distance(const orc_corr *in, int64_t n, float max_dist, orc_corr *out);
+int64_t orc_reject_surface_normal(const orc_corr *in, int64_t n, const float *sn, int sns, const float *tn, int tns,
+                                  double threshold, orc_corr *out);
 int64_t orc_reject_median(const orc_corr *in, int64_t n, double factor, orc_corr *out,
                           double *median);
 int64_t orc_reject_one_to_one(const orc_corr *in, int64_t n, orc_corr *out);

@@ -83,6 +83,9 @@ def lib():
         for name in ("orc_reject_distance",):
             getattr(L, name).restype = c_i64
         L.orc_reject_distance.argtypes = [C.c_void_p, c_i64, C.c_float, C.c_void_p]
+        L.orc_reject_surface_normal.restype = c_i64
+        L.orc_reject_surface_normal.argtypes = [C.c_void_p, c_i64, c_f32p, C.c_int, c_f32p, C.c_int, C.c_double,
+                                                C.c_void_p]
         L.orc_reject_median.restype = c_i64
         L.orc_reject_median.argtypes = [C.c_void_p, c_i64, C.c_double, C.c_void_p, C.POINTER(C.c_double)]
         L.orc_reject_one_to_one.restype = c_i64
@@ -290,6 +293,16 @@ def reject_distance(corr, max_dist):
     corr = np.ascontiguousarray(corr, CORR_DTYPE)
     out = np.zeros(len(corr), CORR_DTYPE)
     n = lib().orc_reject_distance(corr.ctypes.data, len(corr), max_dist, out.ctypes.data)
+    return out[:n].copy()
+
+
+def reject_surface_normal(corr, src_normals, tgt_normals, threshold=1.0):
+    """CorrespondenceRejectorSurfaceNormal (impl/correspondence_rejection_surface_normal.hpp:44-66)."""
+    corr = np.ascontiguousarray(corr, CORR_DTYPE)
+    sn, tn = _f32(src_normals), _f32(tgt_normals)
+    out = np.zeros(len(corr), CORR_DTYPE)
+    n = lib().orc_reject_surface_normal(corr.ctypes.data, len(corr), _p(sn, c_f32p), sn.shape[1], _p(tn, c_f32p),
+                                        tn.shape[1], float(threshold), out.ctypes.data)
     return out[:n].copy()
 
 

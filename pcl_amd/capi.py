@@ -99,6 +99,11 @@ SIGNATURES = {
                                            C.c_void_p, C.POINTER(C.c_size_t), c_f64p, c_f64p]),
     "pclmi_correspondences_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
                                             C.c_double, C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p]),
+    "pclmi_reject_surface_normal": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p,
+                                              C.c_size_t, C.c_size_t, C.c_double, C.c_void_p, C.POINTER(C.c_size_t)]),
+    "pclmi_reject_surface_normal_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t,
+                                                  C.c_void_p, C.c_size_t, C.c_size_t, C.c_double, C.c_void_p,
+                                                  C.POINTER(C.c_size_t), C.c_void_p]),
     "pclmi_reject_distance_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_float, C.c_void_p, C.POINTER(C.c_size_t),
                                             C.c_void_p]),
     "pclmi_reject_median_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_double, C.c_void_p, C.POINTER(C.c_size_t),
@@ -454,6 +459,13 @@ def _rej(fn, corr, *args, extra=()):
 
 def reject_distance(corr, max_distance):
     return _rej(load_library().pclmi_reject_distance, corr, max_distance)
+
+
+def reject_surface_normal(corr, src_normals, tgt_normals, threshold=1.0):
+    """pcl::registration::CorrespondenceRejectorSurfaceNormal: pairs whose normals' dot product is > threshold."""
+    sn, tn = _pts(src_normals), _pts(tgt_normals)
+    return _rej(load_library().pclmi_reject_surface_normal, corr, sn.ctypes.data, len(sn), sn.shape[1] * 4,
+                tn.ctypes.data, len(tn), tn.shape[1] * 4, float(threshold))
 
 
 def reject_median(corr, factor=1.0):

@@ -93,6 +93,22 @@ struct SrcDistLess {  // original.distance < limit (correspondence_rejection_dis
     return r.distance < limit;
   }
 };
+// (double)((ns.x * nt.x + ns.y * nt.y) + ns.z * nt.z) > threshold, the normals looked up through the pair's indices
+// (DataContainer::getCorrespondenceScoreFromNormals, correspondence_rejection.h:254-262; _surface_normal.hpp:59-61)
+struct SrcNormalDot {
+  const Corr *c;
+  const float *sn, *tn;
+  int sn_stride_f, tn_stride_f, n_src, n_tgt;
+  double threshold;
+  __device__ bool get(int i, Corr &r) const {
+    r = c[i];
+    if ((unsigned int)r.index_query >= (unsigned int)n_src || (unsigned int)r.index_match >= (unsigned int)n_tgt)
+      return false;  // (the reference would read past its clouds)
+    const float *a = sn + (size_t)r.index_query * sn_stride_f, *b = tn + (size_t)r.index_match * tn_stride_f;
+    const float dot = __fadd_rn(__fadd_rn(__fmul_rn(a[0], b[0]), __fmul_rn(a[1], b[1])), __fmul_rn(a[2], b[2]));
+    return (double)dot > threshold;
+  }
+};
 struct SrcDistLessEqD {  // (double) distance <= limit (correspondence_rejection_median_distance.hpp:64)
   const Corr *c;
   const double *limit;  // device scalar
@@ -413,6 +429,27 @@ int pclmi_reject_distance_dev(const pclmi_correspondence *d_in, size_t n, float 
   return finish_count(g.w, n_out, s);
 }
 
+int pclmi_reject_surface_normal_dev(const pclmi_correspondence *d_in, size_t n, const float *d_src_normals, size_t n_src,
+                                    size_t sn_stride_bytes, const float *d_tgt_normals, size_t n_tgt,
+                                    size_t tn_stride_bytes, double threshold, pclmi_correspondence *d_out,
+                                    size_t *n_out, void *stream) {
+  RC(dev_checks(d_in, n, d_out, n_out));
+  PCLMI_CHECK(n == 0 || (d_src_normals && d_tgt_normals), PCLMI_ERR_INVALID, "NULL normals");
+  PCLMI_CHECK(sn_stride_bytes >= 12 && sn_stride_bytes % 4 == 0 && tn_stride_bytes >= 12 && tn_stride_bytes % 4 == 0,
+              PCLMI_ERR_INVALID, "bad stride");
+  PCLMI_CHECK(n_src < ((size_t)1 << 31) && n_tgt < ((size_t)1 << 31), PCLMI_ERR_UNSUPPORTED, "more than 2^31-1 normals");
+  if (n == 0) return PCLMI_OK;
+  RejGuard g;
+  if (!g.w) return PCLMI_ERR_HIP;
+  hipStream_t s = (hipStream_t)stream;
+  RC(g.w->ensure(B_SMALL, sizeof(Small)));
+  RC(compact(g.w,
+             SrcNormalDot{d_in, d_src_normals, d_tgt_normals, (int)(sn_stride_bytes / 4), (int)(tn_stride_bytes / 4),
+                          (int)n_src, (int)n_tgt, threshold},
+             n, d_out, &((Small *)g.w->buf[B_SMALL])->count, s));
+  return finish_count(g.w, n_out, s);
+}
+
 int pclmi_reject_median_dev(const pclmi_correspondence *d_in, size_t n, double factor, pclmi_correspondence *d_out,
                             size_t *n_out, double *median, void *stream) {
   RC(dev_checks(d_in, n, d_out, n_out));
@@ -553,6 +590,25 @@ int pclmi_reject_distance(const pclmi_correspondence *in, size_t n, float max_di
                           size_t *n_out) {
   return via_host(in, n, out, n_out, [&](const Corr *di, Corr *dout, void *s) {
     return pclmi_reject_distance_dev(di, n, max_distance, dout, n_out, s);
+  });
+}
+
+int pclmi_reject_surface_normal(const pclmi_correspondence *in, size_t n, const float *src_normals, size_t n_src,
+                                size_t sn_stride_bytes, const float *tgt_normals, size_t n_tgt, size_t tn_stride_bytes,
+                                double threshold, pclmi_correspondence *out, size_t *n_out) {
+  PCLMI_CHECK(n_out != nullptr, PCLMI_ERR_INVALID, "n_out is NULL");
+  *n_out = 0;
+  PCLMI_CHECK(n == 0 || (src_normals && tgt_normals), PCLMI_ERR_INVALID, "NULL normals");
+  PCLMI_CHECK(pclmi_device_count() > 0, PCLMI_ERR_NO_DEVICE, "no HIP device visible: libpclmi has no CPU fallback");
+  if (n == 0) return PCLMI_OK;
+  DevBuf<unsigned char> dsn, dtn;
+  RC(dsn.alloc(n_src * sn_stride_bytes));
+  RC(dtn.alloc(n_tgt * tn_stride_bytes));
+  if (n_src) PCLMI_HIP(hipMemcpy(dsn.p, src_normals, n_src * sn_stride_bytes, hipMemcpyHostToDevice));
+  if (n_tgt) PCLMI_HIP(hipMemcpy(dtn.p, tgt_normals, n_tgt * tn_stride_bytes, hipMemcpyHostToDevice));
+  return via_host(in, n, out, n_out, [&](const Corr *di, Corr *dout, void *s) {
+    return pclmi_reject_surface_normal_dev(di, n, (const float *)dsn.p, n_src, sn_stride_bytes, (const float *)dtn.p,
+                                           n_tgt, tn_stride_bytes, threshold, dout, n_out, s);
   });
 }
 

@@ -24,6 +24,7 @@
 #include <pcl/registration/correspondence_rejection_median_distance.h>
 #include <pcl/registration/correspondence_rejection_one_to_one.h>
 #include <pcl/registration/correspondence_rejection_sample_consensus.h>
+#include <pcl/registration/correspondence_rejection_surface_normal.h>
 #include <pcl/registration/correspondence_rejection_trimmed.h>
 #include <pcl/registration/correspondence_rejection_var_trimmed.h>
 #include <pcl/registration/correspondence_estimation_backprojection.h>
@@ -591,6 +592,55 @@ TEST(RegistrationAPI) {
   EXPECT(T2 == Tsvd);
 }
 
+// ---- test/registration/test_registration_api.cpp:219-264 ----------------------------------------------
+TEST(CorrespondenceRejectorSurfaceNormal) {
+  PointCloud<PointXYZ>::Ptr source = cloud_source.makeShared(), target = cloud_target.makeShared();
+  CorrespondencesPtr corr(new Correspondences);
+  registration::CorrespondenceEstimation<PointXYZ, PointXYZ> corr_est;
+  corr_est.setInputCloud(source);
+  corr_est.setInputTarget(target);
+  corr_est.determineCorrespondences(*corr);
+  PointCloud<PointNormal>::Ptr source_normals(new PointCloud<PointNormal>), target_normals(new PointCloud<PointNormal>);
+  copyPointCloud(*source, *source_normals);
+  copyPointCloud(*target, *target_normals);
+  NormalEstimation<PointNormal, PointNormal> norm_est_src, norm_est_tgt;
+  norm_est_src.setSearchMethod(search::KdTree<PointNormal>::Ptr(new search::KdTree<PointNormal>));
+  norm_est_src.setKSearch(10);
+  norm_est_src.setInputCloud(source_normals);
+  norm_est_src.compute(*source_normals);
+  norm_est_tgt.setSearchMethod(search::KdTree<PointNormal>::Ptr(new search::KdTree<PointNormal>));
+  norm_est_tgt.setKSearch(10);
+  norm_est_tgt.setInputCloud(target_normals);
+  norm_est_tgt.compute(*target_normals);
+
+  registration::CorrespondenceRejectorSurfaceNormal rej;
+  rej.initializeDataContainer<PointXYZ, PointNormal>();
+  rej.setInputCloud<PointXYZ>(source);
+  rej.setInputTarget<PointXYZ>(target);
+  rej.setInputNormals<PointXYZ, PointNormal>(source_normals);
+  rej.setTargetNormals<PointXYZ, PointNormal>(target_normals);
+  Correspondences res;
+  rej.setInputCorrespondences(corr);
+  rej.setThreshold(0.5);
+  rej.getCorrespondences(res);
+  // the reference's own check is conditional on the count (:261-263); what the class promises is checked directly:
+  // the kept pairs are exactly those whose normals' fp32 dot product exceeds the threshold, in input order
+  size_t k = 0;
+  for (size_t i = 0; i < corr->size(); ++i) {
+    const PointNormal &a = source_normals->points[(*corr)[i].index_query], &b = target_normals->points[(*corr)[i].index_match];
+    const float dot = (a.normal_x * b.normal_x + a.normal_y * b.normal_y) + a.normal_z * b.normal_z;
+    if (double(dot) > 0.5) {
+      EXPECT(k < res.size() && res[k].index_query == (*corr)[i].index_query && res[k].index_match == (*corr)[i].index_match);
+      ++k;
+    }
+  }
+  EXPECT_EQ(k, res.size());
+  EXPECT(!res.empty() && res.size() < corr->size());
+  const std::vector<double> gold = jsonNumbers(g_dir + "/registration_api.json", "correspondences_dist");
+  if (res.size() * 2 == gold.size())
+    for (size_t i = 0; i < res.size(); ++i) EXPECT_EQ(res[i].index_match, int(gold[2 * i + 1]));
+}
+
 // ---- test/registration/test_registration.cpp:154-188 ------------------------------------------------
 TEST(IterativeClosestPointGolden) {
   IterativeClosestPoint<PointXYZ, PointXYZ> reg;
@@ -761,6 +811,7 @@ int main(int argc, char **argv) {
   RUN(CorrespondenceEstimationBackProjection_api);
   RUN(getApproximateIndices_equals_per_point_search);
   RUN(RegistrationAPI);
+  RUN(CorrespondenceRejectorSurfaceNormal);
   RUN(IterativeClosestPointGolden);
   RUN(IterativeClosestPoint_PointToPlaneLLS);
   std::printf("%d checks, %d failed\n", g_checks, g_fail);

@@ -79,6 +79,40 @@ def test_rejectors_vs_oracle_random(capi, orc, n):
             assert (gf, gd) == (of, od) and np.array_equal(g, o)
 
 
+def test_surface_normal_rejector_vs_oracle(capi, orc):
+    """CorrespondenceRejectorSurfaceNormal (impl/correspondence_rejection_surface_normal.hpp:44-66): bun0 -> bun4 pairs
+    with k = 10 normals as the reference test sets it up (test_registration_api.cpp:219-264), and random pairs / normals
+    with NaN normals and every threshold side; bit-exact against the oracle restatement."""
+    src, tgt = util.bun0(), util.bun4()
+    ts, tt = capi.Tree(src), capi.Tree(tgt)
+    sn = capi.normals(ts, src, k=10)[:, :3].copy()
+    tn = capi.normals(tt, tgt, k=10)[:, :3].copy()
+    corr = capi.correspondences(tt, src)
+    for thr in (0.5, 0.9, -1.0, 1.0):
+        g = capi.reject_surface_normal(corr, sn, tn, thr)
+        o = orc.reject_surface_normal(corr, sn, tn, thr)
+        assert np.array_equal(g, o), thr
+    assert 0 < len(capi.reject_surface_normal(corr, sn, tn, 0.5)) < len(corr)
+    rng = np.random.default_rng(99)
+    n, ns, nt = 300_000, 50_000, 40_000
+    from pcl_amd.capi import CORR_DTYPE
+    c = np.zeros(n, CORR_DTYPE)
+    c["index_query"] = rng.integers(0, ns, n)
+    c["index_match"] = rng.integers(0, nt, n)
+    c["distance"] = rng.random(n).astype(np.float32)
+    a = rng.normal(size=(ns, 4)).astype(np.float32)  # 16-byte stride
+    b = rng.normal(size=(nt, 3)).astype(np.float32)
+    a[:, :3] /= np.linalg.norm(a[:, :3], axis=1, keepdims=True)
+    b /= np.linalg.norm(b, axis=1, keepdims=True)
+    a[::97, 1] = np.nan
+    b[::89] = np.nan
+    for thr in (0.0, 0.7):
+        g = capi.reject_surface_normal(c, a, b, thr)
+        o = orc.reject_surface_normal(c, a, b, thr)
+        assert np.array_equal(g, o) and 0 < len(g) < n
+    assert len(capi.reject_surface_normal(c[:0], a, b, 0.0)) == 0
+
+
 def test_var_trimmed_with_ties_at_the_trim_distance(capi, orc):
     """Several distances EQUAL to the trimmed distance: the reference's selection runs over an array that std::sort and
     then nth_element have permuted (_var_trimmed.hpp:64-78,87), so WHICH positions it keeps there depends on
