@@ -60,7 +60,21 @@ class PointRepresentation {
   }
   int getNumberOfDimensions() const { return nr_dimensions_; }
 
+  /** \brief Not in the reference: true when vectorize() is "the point's x, y, z, each times a constant" (1..3
+    * dimensions; missing ones count as 0) and then fills those constants.  That is what the device ICP loop can apply
+    * to a moving source point by itself (Registration::setPointRepresentation); representations that read other
+    * fields or compute something else return false. */
+  virtual bool diagonalScale(float scale[3]) const {
+    (void)scale;
+    return false;
+  }
+
  protected:
+  bool fillScale(float scale[3]) const {
+    if (nr_dimensions_ < 1 || nr_dimensions_ > 3) return false;
+    for (int i = 0; i < 3; ++i) scale[i] = i < nr_dimensions_ ? (alpha_.empty() ? 1.f : alpha_[i]) : 0.f;
+    return true;
+  }
   int nr_dimensions_;
   std::vector<float> alpha_;
   bool trivial_;
@@ -82,6 +96,7 @@ class DefaultPointRepresentation : public PointRepresentation<PointT> {
     out[1] = p.y;
     out[2] = p.z;
   }
+  bool diagonalScale(float scale[3]) const override { return this->fillScale(scale); }
 };
 
 // the first `max_dim` coordinates starting at `start_dim` (CustomPointRepresentation, :497-553)
@@ -100,6 +115,7 @@ class CustomPointRepresentation : public PointRepresentation<PointT> {
     const float *f = reinterpret_cast<const float *>(&p) + start_dim_;
     for (int i = 0; i < this->nr_dimensions_; ++i) out[i] = f[i];
   }
+  bool diagonalScale(float scale[3]) const override { return start_dim_ == 0 && this->fillScale(scale); }
 
  protected:
   int max_dim_, start_dim_;

@@ -84,9 +84,24 @@ class IterativeClosestPoint : public Registration<PointSource, PointTarget> {
                 "with normals (normal_x, normal_y, normal_z)\n", getClassName().c_str());
       return;
     }
-    if (Base::point_representation_ && !Base::point_representation_->isTrivial())
-      PCL_WARN("[pcl::%s::computeTransformation] the point representation applies to the target tree only: the "
-               "correspondence loop reads the source's raw x, y, z\n", getClassName().c_str());
+    // Registration::setPointRepresentation: the reference vectorises the moving source point through the
+    // representation for every search (registration.h:362-370 -> kdtree.h:204-218 -> impl/kdtree_flann.hpp:91-92) and
+    // hands the points themselves to the estimator.  A per-dimension rescale of x, y, z runs inside the device loop
+    // (pclmi_icp_align_scaled); anything else cannot be applied to a point that only exists on the device.
+    float rep_scale[3] = {1.f, 1.f, 1.f};
+    bool scaled = false;
+    if (Base::point_representation_ && !Base::point_representation_->isTrivial()) {
+      scaled = Base::point_representation_->diagonalScale(rep_scale);
+      if (!scaled)
+        PCL_WARN("[pcl::%s::computeTransformation] this point representation is not a rescale of x, y, z: it applies "
+                 "to the target tree only, the correspondence loop reads the source's raw x, y, z\n",
+                 getClassName().c_str());
+      else if (loop == 1 || Base::update_visualizer_) {
+        PCL_ERROR("[pcl::%s::computeTransformation] a rescaling point representation is supported with "
+                  "TransformationEstimationSVD and without a visualization callback\n", getClassName().c_str());
+        return;
+      }
+    }
     pclmi_icp_params p;
     pclmi_icp_default_params(&p);
     p.max_iterations = max_iterations_;
@@ -121,6 +136,12 @@ class IterativeClosestPoint : public Registration<PointSource, PointTarget> {
                                                    Base::target_->points.size(), sizeof(PointTarget),
                                                    guess.isIdentity() ? nullptr : guess.data(), comm_,
                                                    final_transformation_.data(), aligned.data(), &stats_)
+        : scaled ? pclmi_icp_align_scaled(&p, tree_->getDeviceTree(), rep_scale,
+                                          reinterpret_cast<const float *>(Base::target_->points.data()),
+                                          Base::target_->points.size(), sizeof(PointTarget), src_xyz,
+                                          output.points.size(), sizeof(PointSource),
+                                          guess.isIdentity() ? nullptr : guess.data(), comm_,
+                                          final_transformation_.data(), aligned.data(), &stats_)
         : sharded ? pclmi_icp_align_sharded(&p, tree_->getDeviceTree(), src_xyz, output.points.size(), sizeof(PointSource),
                                           guess.isIdentity() ? nullptr : guess.data(), comm_,
                                           final_transformation_.data(), aligned.data(), &stats_)

@@ -97,6 +97,35 @@ class Registration : public PCLBase<PointSource> {
   double getFitnessScore(double max_range = std::numeric_limits<double>::max()) {
     double score = std::numeric_limits<double>::max();
     if (!input_ || !tree_->getDeviceTree()) return score;
+    if (point_representation_ && !point_representation_->isTrivial()) {
+      // the pairs are found in the representation's space (registration.hpp:91 through the tree), the score is
+      // the squared distance between the POINTS of each pair (:87-101): move the input on the host
+      // (transforms.hpp:184-191), vectorise it, ONE batched 1-NN call, fp64 sum over the pairs within max_range
+      const Matrix4f &T = final_transformation_;
+      const size_t n = input_->points.size();
+      std::vector<float> q(n * 3), raw(n * 3);
+      for (size_t i = 0; i < n; ++i) {
+        PointTarget moved = PointTarget();
+        const PointSource &p = input_->points[i];
+        moved.x = raw[3 * i] = ((T(0, 0) * p.x + T(0, 1) * p.y) + T(0, 2) * p.z) + T(0, 3);
+        moved.y = raw[3 * i + 1] = ((T(1, 0) * p.x + T(1, 1) * p.y) + T(1, 2) * p.z) + T(1, 3);
+        moved.z = raw[3 * i + 2] = ((T(2, 0) * p.x + T(2, 1) * p.y) + T(2, 2) * p.z) + T(2, 3);
+        tree_->toXYZ(moved, &q[3 * i]);
+      }
+      std::vector<int> idx;
+      std::vector<float> d2;
+      if (tree_->nearestKSearchBatch(q.data(), n, 12, 1, idx, d2) != 1) return score;
+      double sum = 0.0;
+      int nr = 0;
+      for (size_t i = 0; i < n; ++i) {
+        if (idx[i] < 0 || d2[i] > max_range) continue;  // registration.hpp:94
+        const PointTarget &t = target_->points[idx[i]];
+        const float dx = raw[3 * i] - t.x, dy = raw[3 * i + 1] - t.y, dz = raw[3 * i + 2] - t.z;
+        sum += std::fabs(static_cast<double>((dx * dx + dy * dy) + dz * dz));
+        ++nr;
+      }
+      return nr > 0 ? sum / nr : score;
+    }
     const int rc = pclmi_fitness_score(tree_->getDeviceTree(), reinterpret_cast<const float *>(input_->points.data()),
                                        input_->points.size(), sizeof(PointSource), final_transformation_.data(),
                                        max_range, &score);

@@ -419,6 +419,25 @@ int pclmi_icp_align_sharded(const pclmi_icp_params *p, const pclmi_tree *target,
                             size_t stride_bytes, const float *guess, pclmi_comm *comm, float final_T[16],
                             float *aligned, pclmi_icp_stats *stats);
 
+/* Point representations in ICP ---------------------------------------------------------------
+ * Registration::setPointRepresentation (registration/include/pcl/registration/registration.h:362-370 ->
+ * kdtree/include/pcl/kdtree/kdtree.h:204-218 -> impl/kdtree_flann.hpp:91-92): the reference vectorises the moving
+ * source point through the representation for every search - the tree indexes the representation of the target - and
+ * hands the POINTS THEMSELVES to the estimator, the transform and the convergence criteria.  For the representation
+ * "x, y, z times a constant each" (DefaultPointRepresentation / CustomPointRepresentation with setRescaleValues,
+ * point_representation.h:141-168; 0 for a dimension the representation leaves out) the device loop does the same:
+ *   scaled_target: the tree built from scale * target point (what KdTreeFLANN::setInputCloud builds then);
+ *   tgt:           the target cloud itself (rows as the tree's cloud), read by the estimator;
+ * distances and the max_correspondence_distance test are in the scaled space (they come from the tree, icp.hpp:93),
+ * the moments, the RANSAC step and the transform in the points' own.  SVD estimator only.
+ * pclmi_icp_set_search_scale switches a context (before its first step). */
+int pclmi_icp_set_search_scale(pclmi_icp_ctx *ctx, const float scale[3], const float *tgt, size_t n_tgt,
+                               size_t tgt_stride_bytes);
+int pclmi_icp_align_scaled(const pclmi_icp_params *p, const pclmi_tree *scaled_target, const float scale[3],
+                           const float *tgt, size_t n_tgt, size_t tgt_stride_bytes, const float *src, size_t n_src,
+                           size_t stride_bytes, const float *guess, pclmi_comm *comm /* nullable */, float final_T[16],
+                           float *aligned, pclmi_icp_stats *stats);
+
 /* Point-to-plane ICP ------------------------------------------------------------------------
  * IterativeClosestPoint with setTransformationEstimation (TransformationEstimationPointToPlaneLLS)
  * (registration/include/pcl/registration/registration.h:140-160, impl/icp.hpp:171 calling

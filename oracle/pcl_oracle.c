@@ -1095,7 +1095,7 @@ void orc_estimate_point_to_plane_lls(const float *src, int ss, const float *sn, 
  * transformPointCloud, icp.hpp:174, and the estimator only tests them for finiteness). */
 static int icp_align_core(const orc_icp_params *p, const float *src, int64_t ns, int ss, const float *sn, int sns,
                           const float *tgt, int64_t nt, int ts, const float *tn, int tns, const float *guess,
-                          float final_T[16], float *out, orc_icp_stats *stats, int nthreads) {
+                          float final_T[16], float *out, orc_icp_stats *stats, int nthreads, const float *scale) {
   float T[16], Tprev[16];
   mat4_identity(final_T);
   mat4_identity(T);
@@ -1108,7 +1108,19 @@ static int icp_align_core(const orc_icp_params *p, const float *src, int64_t ns,
     memcpy(target + i * 4, tgt + i * ts, 12);
     target[i * 4 + 3] = 1.f;
   }
-  orc_tree *tree = orc_tree_build(target, nt, 4, 15);
+  /* setPointRepresentation (registration.h:362-370): the tree indexes vectorize(target point) = alpha * (x, y, z)
+   * (point_representation.h:141-168, impl/kdtree_flann.hpp:216-244), the searches vectorize the moved source point
+   * the same way (kdtree.h:204-218, impl/kdtree_flann.hpp:91-92); everything else reads the points themselves. */
+  float *vtarget = target, *vq = NULL;
+  if (scale) {
+    vtarget = (float *)malloc((size_t)nt * 4 * sizeof(float));
+    vq = (float *)malloc((size_t)ns * 4 * sizeof(float));
+    for (int64_t i = 0; i < nt; ++i) {
+      for (int c = 0; c < 3; ++c) vtarget[i * 4 + c] = target[i * 4 + c] * scale[c];
+      vtarget[i * 4 + 3] = 1.f;
+    }
+  }
+  orc_tree *tree = orc_tree_build(vtarget, nt, 4, 15);
   /* registration.hpp:149-163: output <- input, w = 1 */
   for (int64_t i = 0; i < ns; ++i) {
     memcpy(out + i * 4, src + i * ss, 12);
@@ -1140,7 +1152,11 @@ static int icp_align_core(const orc_icp_params *p, const float *src, int64_t ns,
   while (!converged) { /* icp.hpp:72 */
     memcpy(Tprev, T, sizeof(T));
     memcpy(dprev, dcur, (size_t)ns * sizeof(float));
-    orc_tree_knn(tree, out, ns, 4, 1, nn_i, nn_d, nthreads);
+    if (scale) {
+      for (int64_t i = 0; i < ns; ++i)
+        for (int c = 0; c < 3; ++c) vq[i * 4 + c] = out[i * 4 + c] * scale[c];
+    }
+    orc_tree_knn(tree, scale ? vq : out, ns, 4, 1, nn_i, nn_d, nthreads);
     cnt = 0;
     for (int64_t i = 0; i < ns; ++i) {
       if ((double)nn_d[i] < dist_threshold) { /* strict: icp.hpp:93 */
@@ -1196,14 +1212,21 @@ static int icp_align_core(const orc_icp_params *p, const float *src, int64_t ns,
   }
   free(dcur); free(dprev); free(nn_i); free(nn_d); free(si); free(ti); free(inl); free(sg); free(tg);
   orc_tree_free(tree);
+  if (scale) { free(vtarget); free(vq); }
   free(target);
   return rc;
+}
+
+int orc_icp_align_scaled(const orc_icp_params *p, const float scale[3], const float *src, int64_t ns, int ss,
+                         const float *tgt, int64_t nt, int ts, const float *guess, float final_T[16], float *out,
+                         orc_icp_stats *stats, int nthreads) {
+  return icp_align_core(p, src, ns, ss, NULL, 0, tgt, nt, ts, NULL, 0, guess, final_T, out, stats, nthreads, scale);
 }
 
 int orc_icp_align(const orc_icp_params *p, const float *src, int64_t ns, int ss, const float *tgt,
                   int64_t nt, int ts, const float *guess, float final_T[16], float *out,
                   orc_icp_stats *stats, int nthreads) {
-  return icp_align_core(p, src, ns, ss, NULL, 0, tgt, nt, ts, NULL, 0, guess, final_T, out, stats, nthreads);
+  return icp_align_core(p, src, ns, ss, NULL, 0, tgt, nt, ts, NULL, 0, guess, final_T, out, stats, nthreads, NULL);
 }
 
 int orc_icp_align_point_to_plane(const orc_icp_params *p, const float *src, int64_t ns, int ss, const float *sn,
@@ -1211,7 +1234,7 @@ int orc_icp_align_point_to_plane(const orc_icp_params *p, const float *src, int6
                                  const float *guess, float final_T[16], float *out, orc_icp_stats *stats,
                                  int nthreads) {
   if (!tn) return -1;
-  return icp_align_core(p, src, ns, ss, sn, sns, tgt, nt, ts, tn, tns, guess, final_T, out, stats, nthreads);
+  return icp_align_core(p, src, ns, ss, sn, sns, tgt, nt, ts, tn, tns, guess, final_T, out, stats, nthreads, NULL);
 }
 
 double orc_fitness_score(const float *src, int64_t ns, int ss, const float *tgt, int64_t nt,

@@ -143,6 +143,14 @@ int orc_icp_align(const orc_icp_params *p, const float *src, int64_t ns, int sst
                   const float *tgt, int64_t nt, int tstride, const float *guess,
                   float final_T[16], float *aligned, orc_icp_stats *stats, int nthreads);
 
+/* The same loop with Registration::setPointRepresentation (registration.h:362-370) for a representation that
+ * rescales x, y, z (point_representation.h:141-168): the tree indexes scale * target point, every search vectorises
+ * the moved source point the same way (kdtree.h:204-218, impl/kdtree_flann.hpp:91-92); the estimator, RANSAC and
+ * the transform read the points themselves. */
+int orc_icp_align_scaled(const orc_icp_params *p, const float scale[3], const float *src, int64_t ns, int sstride,
+                         const float *tgt, int64_t nt, int tstride, const float *guess, float final_T[16],
+                         float *aligned, orc_icp_stats *stats, int nthreads);
+
 /* The same loop with setTransformationEstimation (TransformationEstimationPointToPlaneLLS)
  * (registration/include/pcl/registration/registration.h:140-160; icp.hpp:171 then calls
  * impl/transformation_estimation_point_to_plane_lls.hpp:83-101,141-245 on the *_good index lists).

@@ -102,6 +102,8 @@ def lib():
         L.orc_icp_align.restype = C.c_int
         L.orc_icp_align.argtypes = [C.POINTER(IcpParams), c_f32p, c_i64, C.c_int, c_f32p, c_i64, C.c_int, c_f32p,
                                     c_f32p, c_f32p, C.POINTER(IcpStats), C.c_int]
+        L.orc_icp_align_scaled.restype = C.c_int
+        L.orc_icp_align_scaled.argtypes = [C.POINTER(IcpParams), c_f32p] + list(L.orc_icp_align.argtypes[1:])
         L.orc_icp_align_point_to_plane.restype = C.c_int
         L.orc_icp_align_point_to_plane.argtypes = [C.POINTER(IcpParams), c_f32p, c_i64, C.c_int, c_f32p, C.c_int,
                                                    c_f32p, c_i64, C.c_int, c_f32p, C.c_int, c_f32p, c_f32p, c_f32p,
@@ -366,6 +368,21 @@ def icp_align(src, tgt, params=None, guess=None, nthreads=1):
     rc = lib().orc_icp_align(C.byref(p), _p(src, c_f32p), len(src), src.shape[1], _p(tgt, c_f32p), len(tgt),
                              tgt.shape[1], _p(g, c_f32p) if g is not None else None, _p(T, c_f32p),
                              _p(out, c_f32p), C.byref(st), nthreads)
+    return rc, T.reshape(4, 4), out, st
+
+
+def icp_align_scaled(scale, src, tgt, params=None, guess=None, nthreads=1):
+    """ICP with a rescaling point representation (registration.h:362-370): searches in scale * (x, y, z)."""
+    src, tgt = _f32(src), _f32(tgt)
+    sc = np.ascontiguousarray(scale, np.float32).reshape(3)
+    p = params or icp_default_params()
+    T = np.zeros(16, np.float32)
+    out = np.zeros((len(src), 4), np.float32)
+    st = IcpStats()
+    g = np.ascontiguousarray(guess, np.float32).reshape(16) if guess is not None else None
+    rc = lib().orc_icp_align_scaled(C.byref(p), _p(sc, c_f32p), _p(src, c_f32p), len(src), src.shape[1],
+                                    _p(tgt, c_f32p), len(tgt), tgt.shape[1], _p(g, c_f32p) if g is not None else None,
+                                    _p(T, c_f32p), _p(out, c_f32p), C.byref(st), nthreads)
     return rc, T.reshape(4, 4), out, st
 
 

@@ -154,6 +154,9 @@ SIGNATURES = {
     "pclmi_icp_begin_sharded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, c_f32p, C.c_int, C.c_int,
                                           C.POINTER(C.c_void_p)]),
     "pclmi_icp_shard_size": (C.c_size_t, [C.c_void_p]),
+    "pclmi_icp_align_scaled": (C.c_int, [C.c_void_p, C.c_void_p, c_f32p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p,
+                                         C.c_size_t, C.c_size_t, c_f32p, C.c_void_p, c_f32p, C.c_void_p, C.c_void_p]),
+    "pclmi_icp_set_search_scale": (C.c_int, [C.c_void_p, c_f32p, C.c_void_p, C.c_size_t, C.c_size_t]),
     "pclmi_icp_align_sharded": (C.c_int, [C.POINTER(IcpParams), C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t,
                                           c_f32p, C.c_void_p, c_f32p, C.c_void_p, C.POINTER(IcpStats)]),
     "pclmi_icp_set_point_to_plane": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
@@ -541,6 +544,25 @@ def icp_align(target_tree, src, params=None, guess=None):
     rc = lib.pclmi_icp_align(C.byref(p), target_tree.h, s.ctypes.data, len(s), s.shape[1] * 4,
                              None if g is None else g.ctypes.data_as(c_f32p), T.ctypes.data_as(c_f32p),
                              out.ctypes.data, C.byref(st))
+    if rc not in (0, 6):
+        _check(rc)
+    return rc, T.reshape(4, 4), out, st
+
+
+def icp_align_scaled(scaled_target_tree, scale, tgt, src, params=None, guess=None, comm=None):
+    """pclmi_icp_align_scaled: ICP with a rescaling point representation (the tree indexes scale * target)."""
+    lib = load_library()
+    s, t = _pts(src), _pts(tgt)
+    p = params or icp_default_params()
+    T = np.zeros(16, np.float32)
+    out = np.full((len(s), 4), np.nan, np.float32)
+    st = IcpStats()
+    sc = np.ascontiguousarray(scale, np.float32).reshape(3)
+    g = None if guess is None else np.ascontiguousarray(guess, np.float32).reshape(16)
+    rc = lib.pclmi_icp_align_scaled(C.byref(p), scaled_target_tree.h, sc.ctypes.data_as(c_f32p), t.ctypes.data, len(t),
+                                    t.shape[1] * 4, s.ctypes.data, len(s), s.shape[1] * 4,
+                                    None if g is None else g.ctypes.data_as(c_f32p), comm.h if comm else None,
+                                    T.ctypes.data_as(c_f32p), out.ctypes.data, C.byref(st))
     if rc not in (0, 6):
         _check(rc)
     return rc, T.reshape(4, 4), out, st

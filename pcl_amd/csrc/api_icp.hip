@@ -82,6 +82,10 @@ struct pclmi_icp_ctx {
   DevBuf<float4> tn_slot;           // target normals by bucket slot (step kernel)
   DevBuf<unsigned char> src_skip;   // per slot: the source normal is not finite (allocated only when one is)
   bool has_skip = false;
+  // rescaling point representation (pclmi_icp_set_search_scale): the tree holds scale * target point
+  bool scaled = false;
+  float scale[3] = {1.f, 1.f, 1.f};
+  DevBuf<float4> raw_tgt;  // the target's own rows, for the estimator
   int nsums() const { return plane ? PCLMI_ICP_NSUMS_PLANE : PCLMI_ICP_NSUMS; }
   int i_pairs() const { return plane ? 27 : 0; }
   int i_fit() const { return plane ? 29 : 17; }
@@ -409,7 +413,8 @@ static int icp_step_enqueue(pclmi_icp_ctx *c, double max_correspondence_distance
   if (fused && c->comm) tail.comm = comm_view(c->comm);
   launch_icp_step(c->tree, c->pts.p, c->n, c->pending, make_xf(c->T), thr2, c->nn.p, c->nn_slot.p, c->dist.p, c->origin,
                   c->partials.p, s, c->dev_mode ? c->state.p : nullptr, c->stepped, tail,
-                  c->plane ? c->tn_slot.p : nullptr, c->has_skip ? c->src_skip.p : nullptr, d_keep_slot, d_tq);
+                  c->plane ? c->tn_slot.p : nullptr, c->has_skip ? c->src_skip.p : nullptr, d_keep_slot, d_tq,
+                  c->scaled ? c->raw_tgt.p : nullptr, c->scaled ? c->scale : nullptr);
   c->pending = false;
   c->stepped = true;
   PCLMI_HIP(hipGetLastError());
@@ -473,6 +478,22 @@ int pclmi_icp_set_point_to_plane(pclmi_icp_ctx *c, const float *tgt_normals, siz
   }
   PCLMI_HIP(hipStreamSynchronize(c->stream));
   c->plane = true;
+  return PCLMI_OK;
+}
+
+// Registration::setPointRepresentation with a per-dimension rescale (pclmi.h "Point representations in ICP")
+int pclmi_icp_set_search_scale(pclmi_icp_ctx *c, const float scale[3], const float *tgt, size_t n_tgt,
+                               size_t tgt_stride_bytes) {
+  PCLMI_CHECK(c && scale && tgt, PCLMI_ERR_INVALID, "NULL argument");
+  PCLMI_CHECK(!c->stepped && !c->dev_mode, PCLMI_ERR_INVALID, "the search scale must be set before the first step");
+  PCLMI_CHECK(!c->plane, PCLMI_ERR_UNSUPPORTED, "the point-to-plane loop has no rescaled search");
+  PCLMI_CHECK(tgt_stride_bytes >= 12 && tgt_stride_bytes % 4 == 0, PCLMI_ERR_INVALID, "bad stride");
+  PCLMI_CHECK(n_tgt >= c->tree->rows, PCLMI_ERR_INVALID, "%zu target rows for a tree built from %zu", n_tgt,
+              (size_t)c->tree->rows);
+  PCLMI_HIP(hipSetDevice(c->tree->device));
+  RC(upload_packed(tgt, c->tree->rows, tgt_stride_bytes, nullptr, 0, c->raw_tgt, c->stream));
+  for (int d = 0; d < 3; ++d) c->scale[d] = scale[d];
+  c->scaled = true;
   return PCLMI_OK;
 }
 
@@ -1003,6 +1024,11 @@ struct PlaneArgs {
   const float *tgt_normals;
   size_t n_tgt, tn_stride;
 };
+struct ScaleArgs {  // a rescaling point representation: the tree indexes scale * target point
+  const float *scale;
+  const float *tgt;
+  size_t n_tgt, tgt_stride;
+};
 
 // Per-iteration observer (Registration::registerVisualizationCallback, registration.h update_visualizer_, called at
 // icp.hpp:182-183): after every iteration the moved source and the pairs the estimator was given go to the host.
@@ -1081,7 +1107,8 @@ struct Observer {
 // Registration::align for both estimators, on one GPU or over the ranks of `comm`
 int align_core(const pclmi_icp_params *p, const pclmi_tree *target, const float *src, size_t n_src, size_t stride_bytes,
                const float *guess, pclmi_comm *comm, const PlaneArgs *plane, float final_T[16], float *aligned,
-               pclmi_icp_stats *stats, pclmi_icp_iteration_fn on_iteration = nullptr, void *user = nullptr) {
+               pclmi_icp_stats *stats, pclmi_icp_iteration_fn on_iteration = nullptr, void *user = nullptr,
+               const ScaleArgs *scale = nullptr) {
   PCLMI_CHECK(p && target && final_T, PCLMI_ERR_INVALID, "NULL argument");
   Observer obs;
   obs.fn = on_iteration;
@@ -1095,6 +1122,8 @@ int align_core(const pclmi_icp_params *p, const pclmi_tree *target, const float 
   const int world = comm ? pclmi_comm_size(comm) : 1;
   PCLMI_CHECK(world == 1 || !comm_dead(comm), PCLMI_ERR_COMM,
               "an earlier exchange of this communicator timed out: destroy it and create a new one on every rank");
+  PCLMI_CHECK(!(scale && on_iteration), PCLMI_ERR_UNSUPPORTED,
+              "the per-iteration observer is not available with a rescaled search");
   PCLMI_CHECK(!on_iteration || world == 1, PCLMI_ERR_UNSUPPORTED,
               "the per-iteration observer sees the whole source: it is not available for a sharded align");
   pclmi_icp_ctx *c = nullptr;
@@ -1104,6 +1133,7 @@ int align_core(const pclmi_icp_params *p, const pclmi_tree *target, const float 
   if (plane)
     rc = pclmi_icp_set_point_to_plane(c, plane->tgt_normals, plane->n_tgt, plane->tn_stride, plane->src_normals, n_src,
                                       plane->sn_stride);
+  if (!rc && scale) rc = pclmi_icp_set_search_scale(c, scale->scale, scale->tgt, scale->n_tgt, scale->tgt_stride);
   if (!rc && p->ransac_iterations <= 0) {
     // no RANSAC step: the whole loop runs on the device, ONE kernel per iteration (step, reduction, exchange with the
     // other ranks, solve); the host only looks at the state every few iterations to stop enqueueing once a criterion
@@ -1221,6 +1251,16 @@ int pclmi_icp_align(const pclmi_icp_params *p, const pclmi_tree *target, const f
                     size_t stride_bytes, const float *guess, float final_T[16], float *aligned,
                     pclmi_icp_stats *stats) {
   return align_core(p, target, src, n_src, stride_bytes, guess, nullptr, nullptr, final_T, aligned, stats);
+}
+
+int pclmi_icp_align_scaled(const pclmi_icp_params *p, const pclmi_tree *scaled_target, const float scale[3],
+                           const float *tgt, size_t n_tgt, size_t tgt_stride_bytes, const float *src, size_t n_src,
+                           size_t stride_bytes, const float *guess, pclmi_comm *comm, float final_T[16], float *aligned,
+                           pclmi_icp_stats *stats) {
+  PCLMI_CHECK(scale && tgt, PCLMI_ERR_INVALID, "NULL argument");
+  const ScaleArgs sa{scale, tgt, n_tgt, tgt_stride_bytes};
+  return align_core(p, scaled_target, src, n_src, stride_bytes, guess, comm, nullptr, final_T, aligned, stats, nullptr,
+                    nullptr, &sa);
 }
 
 int pclmi_icp_align_sharded(const pclmi_icp_params *p, const pclmi_tree *target, const float *src, size_t n_src,

@@ -431,7 +431,7 @@ __device__ __forceinline__ void icp_step_tail(const IcpTail &tail, double *__res
 // lane has just found), src_skip (nullable) flags source points whose own normal is not finite (:158-174 skips them).
 // RS: the step of the RANSAC loop (pclmi_icp_align with ransac_iterations > 0): also leaves keep_slot[slot] = "this
 // point has a pair" for the passes of the rejection step and adds the paired source points' second moments.
-template <bool LANE, int EST, bool RS>
+template <bool LANE, int EST, bool RS, bool SC>
 __global__ __launch_bounds__(64 * ICP_WPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void icp_step_kernel(TreeView t, float4 *__restrict__ pts, int n,
                                                                  int apply, Xf T, float thr2f, double thr2,
                                                                  int *__restrict__ nn_idx, int *__restrict__ nn_slot,
@@ -442,8 +442,11 @@ __global__ __launch_bounds__(64 * ICP_WPB) __attribute__((amdgpu_waves_per_eu(8,
                                                                  const float4 *__restrict__ tn_slot,
                                                                  const unsigned char *__restrict__ src_skip,
                                                                  unsigned char *__restrict__ keep_slot,
-                                                                 float4 *__restrict__ tq) {
+                                                                 float4 *__restrict__ tq,
+                                                                 const float4 *__restrict__ raw_tgt, float ax, float ay,
+                                                                 float az) {
   static_assert(LANE || !EST, "the point-to-plane loop reads the target normals by bucket slot");
+  static_assert(!SC || !EST, "the rescaled search is the SVD estimator's");
   extern __shared__ float far_lds[];
   __shared__ double lds[ICP_WPB][SumsOf<EST, RS>::n];
   if (st) {  // device-resident loop: the pending transform and the stop flag live in device memory
@@ -493,6 +496,16 @@ __global__ __launch_bounds__(64 * ICP_WPB) __attribute__((amdgpu_waves_per_eu(8,
     }
     const bool searchable = alive && finite3(p);
     if (!searchable) p.x = p.y = p.z = __builtin_nanf("");
+    // the search runs in the tree's point representation (a per-dimension rescale of x, y, z: Registration::
+    // setPointRepresentation, registration.h:362-370 -> kdtree.h:204-218 vectorises the query); the estimator below
+    // reads the points themselves.  !SC: the representation is the identity (its own instantiation: the plain step
+    // keeps its registers).
+    float vx = p.x, vy = p.y, vz = p.z;
+    if (SC) {
+      vx = __fmul_rn(p.x, ax);
+      vy = __fmul_rn(p.y, ay);
+      vz = __fmul_rn(p.z, az);
+    }
     PCLMI_WALK_STAMP(1);
     unsigned long long best;
     int bslot = 0;
@@ -502,21 +515,21 @@ __global__ __launch_bounds__(64 * ICP_WPB) __attribute__((amdgpu_waves_per_eu(8,
       const int j = nn_slot[slot];
       if (j >= 0) {  // the previous neighbour is an indexed point: its distance bounds the new nearest one
         const float4 o = rows[j];
-        tau0 = sq3(p.x - o.x, p.y - o.y, p.z - o.z);
+        tau0 = sq3(vx - o.x, vy - o.y, vz - o.z);
         start_leaf = t.M + j / L;
       }
     }
     PCLMI_WALK_STAMP(2);
-    const int root = have_prev ? wave_common_root(t, p.x, p.y, p.z, searchable, tau0) : 1;
+    const int root = have_prev ? wave_common_root(t, vx, vy, vz, searchable, tau0) : 1;
     PCLMI_WALK_STAMP(3);
     if (LANE) {
-      best = lane_nearest(t, p.x, p.y, p.z, searchable, tau0,
+      best = lane_nearest(t, vx, vy, vz, searchable, tau0,
                           reinterpret_cast<float(*)[64]>(far_lds + (size_t)wib * levels * 64), lane, root, bslot,
                           start_leaf);
     } else {
       // wave-uniform walk below the common root; lanes without a previous neighbour (first step, or the point was
       // not searchable then) have an infinite bound, which only keeps the root at 1
-      best = wave_nearest(t, p.x, p.y, p.z, searchable, lane, have_prev != 0, tau0, root, &bslot);
+      best = wave_nearest(t, vx, vy, vz, searchable, lane, have_prev != 0, tau0, root, &bslot);
     }
     PCLMI_WALK_STAMP(4);
     if (alive) {
@@ -531,7 +544,7 @@ __global__ __launch_bounds__(64 * ICP_WPB) __attribute__((amdgpu_waves_per_eu(8,
         dist[slot] = dc;
         counted = true;
         if ((double)d < thr2) {  // strict, icp.hpp:93
-          q = rows[bslot];
+          q = SC ? raw_tgt[idx] : rows[bslot];
           paired = true;
           if (RS) tq[slot] = q;  // the rejection step's passes read the matched point in storage order
           if (EST) {
@@ -2015,27 +2028,40 @@ unsigned icp_step_groups(size_t n) { return (icp_step_blocks(n) + ICP_GROUP - 1)
 void launch_icp_step(const pclmi_tree *t, float4 *d_pts, size_t n, bool apply, const Xf &T, double thr2,
                      int *d_nn, int *d_nn_slot, float *d_dist, const double origin[3], double *d_partials,
                      hipStream_t s, IcpDevState *st, bool have_prev, const IcpTail &tail, const float4 *d_tn_slot,
-                     const unsigned char *d_src_skip, unsigned char *d_keep_slot, float4 *d_tq) {
+                     const unsigned char *d_src_skip, unsigned char *d_keep_slot, float4 *d_tq, const float4 *d_raw_tgt,
+                     const float *scale) {
+  const float sc[3] = {scale ? scale[0] : 1.f, scale ? scale[1] : 1.f, scale ? scale[2] : 1.f};
   const unsigned blocks = icp_step_blocks(n);
   const bool plane = d_tn_slot != nullptr;  // the point-to-plane loop always walks per lane
   const bool rsv = d_keep_slot != nullptr;  // the RANSAC loop's step
   const int levels = (plane || nn1_per_lane()) ? lane_nearest_levels(t->M) : 0;
   TimingScope ts(PCLMI_TIMER_ICP_STEP, s);
   const size_t lds_bytes = (size_t)ICP_WPB * levels * 64 * sizeof(float);
-#define PCLMI_STEP_LAUNCH(LANE_, EST_, RS_, LDS_)                                                                      \
-  hipLaunchKernelGGL((icp_step_kernel<LANE_, EST_, RS_>), dim3(blocks), dim3(64 * ICP_WPB), LDS_, s, t->view(), d_pts, \
+  const bool scl = d_raw_tgt != nullptr;    // searches in a rescaled space (api_icp.hip refuses it with the plane loop)
+#define PCLMI_STEP_LAUNCH(LANE_, EST_, RS_, SC_, LDS_)                                                                      \
+  hipLaunchKernelGGL((icp_step_kernel<LANE_, EST_, RS_, SC_>), dim3(blocks), dim3(64 * ICP_WPB), LDS_, s, t->view(), d_pts, \
                      (int)n, apply ? 1 : 0, T, (float)thr2, thr2, d_nn, d_nn_slot, d_dist, origin[0], origin[1],        \
                      origin[2], d_partials, (const IcpDevState *)st, levels, have_prev ? 1 : 0, tail, d_tn_slot,        \
-                     d_src_skip, d_keep_slot, d_tq)
+                     d_src_skip, d_keep_slot, d_tq, d_raw_tgt, sc[0], sc[1], sc[2])
   if (plane) {
-    if (rsv) PCLMI_STEP_LAUNCH(true, 1, true, lds_bytes);
-    else PCLMI_STEP_LAUNCH(true, 1, false, lds_bytes);
+    if (rsv) PCLMI_STEP_LAUNCH(true, 1, true, false, lds_bytes);
+    else PCLMI_STEP_LAUNCH(true, 1, false, false, lds_bytes);
   } else if (levels > 0) {
-    if (rsv) PCLMI_STEP_LAUNCH(true, 0, true, lds_bytes);
-    else PCLMI_STEP_LAUNCH(true, 0, false, lds_bytes);
+    if (scl) {
+      if (rsv) PCLMI_STEP_LAUNCH(true, 0, true, true, lds_bytes);
+      else PCLMI_STEP_LAUNCH(true, 0, false, true, lds_bytes);
+    } else {
+      if (rsv) PCLMI_STEP_LAUNCH(true, 0, true, false, lds_bytes);
+      else PCLMI_STEP_LAUNCH(true, 0, false, false, lds_bytes);
+    }
   } else {
-    if (rsv) PCLMI_STEP_LAUNCH(false, 0, true, 0);
-    else PCLMI_STEP_LAUNCH(false, 0, false, 0);
+    if (scl) {
+      if (rsv) PCLMI_STEP_LAUNCH(false, 0, true, true, 0);
+      else PCLMI_STEP_LAUNCH(false, 0, false, true, 0);
+    } else {
+      if (rsv) PCLMI_STEP_LAUNCH(false, 0, true, false, 0);
+      else PCLMI_STEP_LAUNCH(false, 0, false, false, 0);
+    }
   }
 #undef PCLMI_STEP_LAUNCH
 }

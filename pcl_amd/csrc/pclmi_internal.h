@@ -316,7 +316,10 @@ void launch_icp_step(const pclmi_tree *t, float4 *d_pts, size_t n, bool apply, c
                      hipStream_t s, IcpDevState *st, bool have_prev, const IcpTail &tail,
                      const float4 *d_tn_slot = nullptr, const unsigned char *d_src_skip = nullptr,
                      unsigned char *d_keep_slot = nullptr /* non-null: the RANSAC loop's step (8 more sums) */,
-                     float4 *d_tq = nullptr /* with d_keep_slot: the matched target point per slot */);
+                     float4 *d_tq = nullptr /* with d_keep_slot: the matched target point per slot */,
+                     const float4 *d_raw_tgt = nullptr /* non-null: the tree indexes scale * point (a rescaling point
+                                                           representation); the estimator reads these rows */,
+                     const float *scale = nullptr);
 // point-to-plane loop (d_tn_slot != nullptr above): PCLMI_ICP_NSUMS_PLANE sums per launch
 void launch_pair_reduce_plane(const float4 *src, const int *sidx, const float4 *tgt, const int *tidx, const float4 *tn,
                               const unsigned char *src_skip, const unsigned char *flags, size_t n, double *d_partials,

@@ -728,6 +728,91 @@ TEST(IterativeClosestPointGolden) {
   EXPECT(!reg.hasConverged());  // icp.hpp:103-108
 }
 
+// Registration::setPointRepresentation (registration.h:362-370): a rescale of x, y, z runs inside the device loop;
+// the result is the C ABI's scaled entry point on the same data, the trivial rescale is the plain loop bit for bit,
+// and a representation that is not a rescale of x, y, z is announced.
+TEST(IterativeClosestPoint_setPointRepresentation) {
+  typedef IterativeClosestPoint<PointXYZ, PointXYZ> ICP;
+  auto run = [&](ICP &reg, PointCloud<PointXYZ> &out) {
+    reg.setInputCloud(cloud_source.makeShared());
+    reg.setInputTarget(cloud_target.makeShared());
+    reg.setMaximumIterations(50);
+    reg.setTransformationEpsilon(1e-8);
+    reg.setMaxCorrespondenceDistance(0.05);
+    reg.align(out);
+  };
+  ICP plain;
+  PointCloud<PointXYZ> out_plain;
+  run(plain, out_plain);
+  const Matrix4f Tp = plain.getFinalTransformation();
+  {
+    std::shared_ptr<DefaultPointRepresentation<PointXYZ> > ones(new DefaultPointRepresentation<PointXYZ>);
+    const float a[3] = {1.f, 1.f, 1.f};
+    ones->setRescaleValues(a);
+    ICP reg;
+    reg.setPointRepresentation(ones);
+    PointCloud<PointXYZ> out;
+    run(reg, out);
+    EXPECT(reg.hasConverged());
+    Matrix4f T = reg.getFinalTransformation();
+    for (int i = 0; i < 16; ++i) EXPECT(T.data()[i] == Tp.data()[i]);
+    EXPECT_NEAR(reg.getFitnessScore(), plain.getFitnessScore(), 1e-12);
+  }
+  {
+    std::shared_ptr<DefaultPointRepresentation<PointXYZ> > rep(new DefaultPointRepresentation<PointXYZ>);
+    const float a[3] = {1.f, 0.5f, 2.f};
+    rep->setRescaleValues(a);
+    ICP reg;
+    reg.setPointRepresentation(rep);
+    PointCloud<PointXYZ> out;
+    run(reg, out);
+    EXPECT(reg.hasConverged());
+    EXPECT(reg.getFitnessScore() < 0.001);
+    // the C ABI on the same data: a tree over the rescaled target, the raw target beside it
+    std::vector<float> scaled(cloud_target.size() * 3);
+    for (size_t i = 0; i < cloud_target.size(); ++i) {
+      scaled[3 * i] = cloud_target[i].x * a[0];
+      scaled[3 * i + 1] = cloud_target[i].y * a[1];
+      scaled[3 * i + 2] = cloud_target[i].z * a[2];
+    }
+    pclmi_tree *t = nullptr;
+    EXPECT(pclmi_tree_create(scaled.data(), cloud_target.size(), 12, nullptr, 0, 0, &t) == PCLMI_OK);
+    pclmi_icp_params p;
+    pclmi_icp_default_params(&p);
+    p.max_iterations = 50;
+    p.transformation_epsilon = 1e-8;
+    p.max_correspondence_distance = 0.05;
+    float T[16];
+    pclmi_icp_stats st;
+    EXPECT(pclmi_icp_align_scaled(&p, t, a, &cloud_target[0].x, cloud_target.size(), sizeof(PointXYZ),
+                                  &cloud_source[0].x, cloud_source.size(), sizeof(PointXYZ), nullptr, nullptr, T,
+                                  nullptr, &st) == PCLMI_OK);
+    Matrix4f F = reg.getFinalTransformation();
+    for (int i = 0; i < 16; ++i) EXPECT(F.data()[i] == T[i]);
+    EXPECT(st.iterations == reg.getNumberOfIterations());
+    bool differs = false;
+    for (int i = 0; i < 12; ++i) differs = differs || F.data()[i] != Tp.data()[i];
+    EXPECT(differs);  // the rescale changed the pairing
+    for (int i = 0; i < 12; ++i) EXPECT_NEAR(F(i / 4, i % 4), Tp(i / 4, i % 4), 2e-2);  // same basin
+    pclmi_tree_destroy(t);
+  }
+  {
+    // x and y only (CustomPointRepresentation (2, 0), the shape test_kdtree.cpp:336-398 uses): z is ignored by the
+    // search and still moves with the transform
+    std::shared_ptr<CustomPointRepresentation<PointXYZ> > xy(new CustomPointRepresentation<PointXYZ>(2, 0));
+    float s[3];
+    EXPECT(xy->diagonalScale(s) && s[0] == 1.f && s[1] == 1.f && s[2] == 0.f);
+    std::shared_ptr<CustomPointRepresentation<PointXYZ> > yz(new CustomPointRepresentation<PointXYZ>(2, 1));
+    EXPECT(!yz->diagonalScale(s));
+    ICP reg;
+    reg.setPointRepresentation(xy);
+    PointCloud<PointXYZ> out;
+    run(reg, out);
+    EXPECT(reg.hasConverged());
+    EXPECT_EQ(int(out.size()), int(cloud_source.size()));
+  }
+}
+
 // ---- test/registration/test_registration.cpp:240-295 ------------------------------------------------
 // The reference test runs ICP on PointNormal clouds with a point-to-plane estimator set through
 // setTransformationEstimation and only asserts convergence (its matrix check is commented out: "different results on
@@ -813,6 +898,7 @@ int main(int argc, char **argv) {
   RUN(RegistrationAPI);
   RUN(CorrespondenceRejectorSurfaceNormal);
   RUN(IterativeClosestPointGolden);
+  RUN(IterativeClosestPoint_setPointRepresentation);
   RUN(IterativeClosestPoint_PointToPlaneLLS);
   std::printf("%d checks, %d failed\n", g_checks, g_fail);
   return g_fail ? 1 : 0;

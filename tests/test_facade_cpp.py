@@ -20,7 +20,7 @@ def test_reference_tests_through_the_cpp_facade():
     r = _run()
     print(r.stdout[-4000:], r.stderr[-2000:])
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
-    assert "0 failed" in r.stdout and r.stdout.count("[  OK  ]") == 14
+    assert "0 failed" in r.stdout and r.stdout.count("[  OK  ]") == 15
 
 
 def test_facade_binary_links_and_refuses_to_run_without_a_gpu():

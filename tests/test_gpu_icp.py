@@ -186,6 +186,46 @@ def test_synthetic_icp_vs_oracle(capi, orc, n, ransac, maxd):
         assert np.abs(T - T0).max() < 5e-3  # and it actually registers the clouds
 
 
+@pytest.mark.parametrize("scale,ransac", [((1.0, 1.0, 1.0), 0), ((0.5, 2.0, 0.25), 0), ((0.5, 2.0, 0.25), 1000),
+                                          ((1.0, 1.0, 0.0), 0)])
+def test_icp_with_a_rescaling_point_representation(capi, orc, scale, ransac):
+    """Registration::setPointRepresentation (registration.h:362-370): searches in scale * (x, y, z) of the MOVING
+    source point, estimator / RANSAC / transform on the points themselves.  (1, 1, 0) is CustomPointRepresentation(2, 0):
+    the search ignores z."""
+    n = 30000
+    tgt = surface_cloud(n, 141)
+    rng = np.random.default_rng(142)
+    sel = rng.permutation(n)[: (n * 9) // 10]
+    T0 = rigid(1.5, (1, 0.5, 1), (0.3, -0.2, 0.1))
+    src = orc.transform(tgt[sel] + rng.normal(0, 0.01, (len(sel), 3)).astype(np.float32), np.linalg.inv(T0))
+    sc = np.asarray(scale, np.float32)
+    tt = capi.Tree(tgt * sc)  # what KdTreeFLANN::setInputCloud builds under that representation
+    p = capi.icp_default_params()
+    p.max_iterations, p.max_correspondence_distance = 10, 2.0
+    p.ransac_iterations, p.ransac_outlier_threshold = ransac, 0.5
+    rc, T, out, st = capi.icp_align_scaled(tt, sc, tgt, src, p)
+    po = orc.icp_default_params()
+    po.max_iterations, po.max_correspondence_distance = 10, 2.0
+    po.ransac_iterations, po.ransac_outlier_threshold = ransac, 0.5
+    po.svd_scalar_double = 1
+    rco, To, outo, sto = orc.icp_align_scaled(sc, src, tgt, po, nthreads=8)
+    assert rc == 0 and rco == 0
+    assert st.iterations == sto.iterations == 10
+    assert st.last_correspondences == sto.last_correspondences
+    assert np.abs(T - To).max() <= T_TOL, np.abs(T - To).max()
+    assert np.allclose(out[:, :3], outo[:, :3], atol=1e-4)
+    if scale == (1.0, 1.0, 1.0):  # the trivial representation: the plain entry point, bit for bit
+        rc1, T1, out1, st1 = capi.icp_align(capi.Tree(tgt), src, p)
+        assert np.array_equal(T1, T) and np.array_equal(out1, out, equal_nan=True)
+    else:  # and the rescale changes the pairing: not the unscaled result
+        rc1, T1, out1, st1 = capi.icp_align(capi.Tree(tgt), src, p)
+        assert st1.last_correspondences != st.last_correspondences or not np.array_equal(T1, T)
+    # a guess, and a context that already stepped refuses the switch
+    rc, Tg, _, _ = capi.icp_align_scaled(tt, sc, tgt, src, p, guess=T0)
+    rco, Tgo, _, _ = orc.icp_align_scaled(sc, src, tgt, po, guess=T0, nthreads=8)
+    assert rc == 0 and np.abs(Tg - Tgo).max() <= T_TOL
+
+
 def test_icp_guess_threshold_and_not_enough(capi, orc):
     tgt = surface_cloud(20000, 51)
     T0 = rigid(3.0, (0, 0, 1), (0.5, 0.5, 0))
