@@ -61,6 +61,7 @@ struct pclmi_icp_ctx {
   DevBuf<double> sums;
   DevBuf<double> gpart;          // group sums of the step kernel's tail
   DevBuf<unsigned int> tickets;  // [groups] group tickets, then the launch ticket
+  DevBuf<unsigned long long> loopbox;  // the resident loop's rows of tagged granules (allocated at its first launch)
   unsigned groups = 1;
   pclmi_comm *comm = nullptr;    // exchange partner of pclmi_icp_run_dev (pclmi_icp_set_comm)
   double origin[3] = {0, 0, 0};
@@ -393,7 +394,8 @@ int pclmi_icp_begin_sharded(const pclmi_tree *target, const float *src, size_t n
 // fused: the launch's last workgroup also exchanges the sums with the other ranks (when a communicator is attached)
 // and runs the solve; otherwise it only leaves the rank's sums in d_sums
 static int icp_step_enqueue(pclmi_icp_ctx *c, double max_correspondence_distance, double *d_sums, void *stream,
-                            bool fused, unsigned char *d_keep_slot = nullptr, float4 *d_tq = nullptr) {
+                            bool fused, unsigned char *d_keep_slot = nullptr, float4 *d_tq = nullptr,
+                            int loop_iters = 1) {
   PCLMI_CHECK(c && d_sums, PCLMI_ERR_INVALID, "NULL argument");
   PCLMI_CHECK(!(fused && c->comm && comm_dead(c->comm)), PCLMI_ERR_COMM,
               "an earlier exchange of this communicator timed out: destroy it and create a new one on every rank");
@@ -411,10 +413,18 @@ static int icp_step_enqueue(pclmi_icp_ctx *c, double max_correspondence_distance
   tail.solve = (fused && !d_keep_slot) ? 1 : 0;  // the RANSAC loop's step: the refit launch solves
   tail.ngroups = (int)c->groups;
   if (fused && c->comm) tail.comm = comm_view(c->comm);
+  if (loop_iters > 1) {
+    if (!c->loopbox.p) {  // zeros: no tag of a launch (iteration numbers from 1) matches
+      const size_t words = icp_loop_box_words(c->n);
+      RC(c->loopbox.alloc(words));
+      PCLMI_HIP(hipMemsetAsync(c->loopbox.p, 0, words * sizeof(unsigned long long), s));
+    }
+    tail.loopbox = c->loopbox.p;
+  }
   launch_icp_step(c->tree, c->pts.p, c->n, c->pending, make_xf(c->T), thr2, c->nn.p, c->nn_slot.p, c->dist.p, c->origin,
                   c->partials.p, s, c->dev_mode ? c->state.p : nullptr, c->stepped, tail,
                   c->plane ? c->tn_slot.p : nullptr, c->has_skip ? c->src_skip.p : nullptr, d_keep_slot, d_tq,
-                  c->scaled ? c->raw_tgt.p : nullptr, c->scaled ? c->scale : nullptr);
+                  c->scaled ? c->raw_tgt.p : nullptr, c->scaled ? c->scale : nullptr, loop_iters);
   c->pending = false;
   c->stepped = true;
   PCLMI_HIP(hipGetLastError());
@@ -532,8 +542,12 @@ int pclmi_icp_run_dev(pclmi_icp_ctx *c, double max_correspondence_distance, int 
               "pclmi_icp_run_dev after pclmi_icp_set_transform: one context is driven either from the host or "
               "from the device");
   // ONE launch per iteration: the step kernel's last workgroup sums the block partials, exchanges the sums with the
-  // other ranks when a communicator is attached, and runs the solve (icp_kernels.hip icp_step_tail)
+  // other ranks when a communicator is attached, and runs the solve (icp_kernels.hip icp_step_tail).  A shard whose
+  // workgroups are all resident at once runs the iterations inside ONE launch (the resident loop): no launch boundary
+  // between iterations.  Same arithmetic in the same order: the results are the per-iteration launches' bit for bit.
   c->dev_mode = true;
+  if (iterations > 1 && !c->scaled && icp_loop_fits(c->tree, c->n, c->plane))
+    return icp_step_enqueue(c, max_correspondence_distance, c->sums.p, stream, true, nullptr, nullptr, iterations);
   for (int i = 0; i < iterations; ++i) RC(icp_step_enqueue(c, max_correspondence_distance, c->sums.p, stream, true));
   return PCLMI_OK;
 }
@@ -1145,7 +1159,9 @@ int align_core(const pclmi_icp_params *p, const pclmi_tree *target, const float 
     std::memset(&st, 0, sizeof(st));
     set_identity(st.last_transform);
     int enqueued = 0;
-    const int chunk_max = obs.fn ? 1 : world > 1 ? 16 : 8;  // an observer is called after every single iteration
+    // an observer is called after every single iteration; the resident loop (pclmi_icp_run_dev) stops by itself
+    const bool resident = !obs.fn && !c->scaled && icp_loop_fits(c->tree, c->n, c->plane);
+    const int chunk_max = obs.fn ? 1 : resident ? (1 << 30) : world > 1 ? 16 : 8;
     while (!rc) {
       const int chunk = std::max(1, std::min(chunk_max, p->max_iterations - enqueued));
       const int before = st.iterations;

@@ -154,16 +154,32 @@ struct SumsOf {
 // instead of by the solving lane one dependent global load after the other - the solve sits on the critical path of
 // every iteration.  It is read only after the rotation has been computed, so none of it is live (and spilled, under
 // the step kernel's 64-VGPR budget) across that computation.
+// State words that a LATER ITERATION OF THE SAME LAUNCH reads back (the resident loop): agent-scope accesses, which
+// go past the vector L1 and the scalar cache (both may hold the word's value from before the store); AG = false: plain
+template <bool AG, typename V>
+__device__ __forceinline__ void st_state(V *p, V v) {
+  typedef __attribute__((address_space(1))) V *gp;
+  if (AG) __hip_atomic_store((gp)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+template <bool AG, typename V>
+__device__ __forceinline__ V ld_state(const V *p) {
+  typedef __attribute__((address_space(1))) const V *gp;
+  if (AG) return __hip_atomic_load((gp)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return *p;
+}
+
 struct SolveIn {
   float T[16], F[16];
   int min_corr, iterations, max_iter, pad;
   double teps, feps;
 };
+template <bool AG = false>
 __device__ __forceinline__ void fetch_solve_in(const IcpDevState *__restrict__ st, SolveIn *in, int lane) {
-  if (lane < 16) in->T[lane] = st->T[lane];
-  else if (lane < 32) in->F[lane - 16] = st->final_T[lane - 16];
+  if (lane < 16) in->T[lane] = ld_state<AG>(&st->T[lane]);
+  else if (lane < 32) in->F[lane - 16] = ld_state<AG>(&st->final_T[lane - 16]);
   else if (lane == 32) in->min_corr = st->min_correspondences;
-  else if (lane == 33) in->iterations = st->iterations;
+  else if (lane == 33) in->iterations = ld_state<AG>(&st->iterations);
   else if (lane == 34) in->max_iter = st->max_iterations;
   else if (lane == 35) in->teps = st->transformation_epsilon;
   else if (lane == 36) in->feps = st->euclidean_fitness_epsilon;
@@ -185,11 +201,17 @@ __device__ __forceinline__ void icp_solve_body(const double *__restrict__ sums, 
     return;
   }
   float Tprev[16], T[16], F[16];
+#ifdef PCLMI_SOLVE_TICKS
+  st->walk[0] = (unsigned long long)wall_clock64();
+#endif
   if (!(EST ? rs::solve_point_to_plane_sums(h, T, work) : rs::solve_from_sums(h, T, work))) {
     st->status = PCLMI_ERR_NOT_ENOUGH;
     st->done = 1;
     return;
   }
+#ifdef PCLMI_SOLVE_TICKS
+  st->walk[1] = (unsigned long long)wall_clock64();
+#endif
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     Tprev[i] = in->T[i];
@@ -421,6 +443,217 @@ __device__ __forceinline__ void icp_step_tail(const IcpTail &tail, double *__res
   }
 }
 
+// ---- the RESIDENT loop's hand-offs (icp_step_kernel<.., LOOP>) --------------------------------------------------
+// Every workgroup of the launch is on the chip at once, so a workgroup may WAIT for another one.  That replaces the
+// arrival tickets (store, drain, atomic, read: four memory round trips per level) by data that announces itself, the
+// scheme of comm_dev.hpp: a double travels as two 8-byte granules {tag = iteration number since the context began,
+// 32 payload bits}, each written by one agent-scope store and polled with agent-scope loads; a granule is either the
+// old one or the new one, the tag says which.  Workgroup b leaves its NS block sums in row b; the first workgroup of
+// every group of ICP_GROUP polls its group's rows and leaves the group sums in the group's row; workgroup 0 polls
+// those, exchanges with the other ranks, solves and PUBLISHES the next transform (12 floats + the stop flag) the same
+// way; every wavefront of the launch polls the publication and goes on with the next iteration.  The additions are
+// the ticket path's, in the same order (tail_column_sum): the sums are the per-iteration launches' bit for bit.
+// Every wait is bounded; a wait that runs out ends the launch with an error in the state.
+constexpr int kLoopRow = 64;  // granules per row: 2 * (sums of the point-to-plane loop)
+typedef __attribute__((address_space(1))) unsigned long long *gl_u64p;
+typedef __attribute__((address_space(1))) const unsigned long long *gl_cu64p;
+__device__ __forceinline__ void put_granules(unsigned long long *dst, double v, unsigned long long tg) {
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+  __hip_atomic_store((gl_u64p)dst, tg | (unsigned int)bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store((gl_u64p)(dst + 1), tg | (unsigned int)(bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long ld_granule(const unsigned long long *p) {
+  return __hip_atomic_load((gl_cu64p)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// tail_column_sum over rows that announce themselves: entry i of the column is the granule pair at base + i * kLoopRow.
+// All of a lane's entries (<= 8: cnt <= 64) are fetched in one batch and the batch is repeated until every tag of the
+// wavefront matches.  ok = false when the data did not arrive within `limit` ticks.
+__device__ __forceinline__ double poll_column_sum(const unsigned long long *base, int cnt, int r, bool active,
+                                                  unsigned int tag, unsigned long long limit, bool &ok) {
+  unsigned long long a[8], b[8];
+  const long long t0 = wall_clock64();
+  unsigned int spins = 0;
+  for (;;) {
+    bool all = true;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int i = r + 8 * j;
+      const bool mine = active && i < cnt;
+      const unsigned long long *src = base + (size_t)(mine ? i : 0) * kLoopRow;
+      a[j] = mine ? ld_granule(src) : ((unsigned long long)tag << 32);
+      b[j] = mine ? ld_granule(src + 1) : ((unsigned long long)tag << 32);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) all = all && (unsigned int)(a[j] >> 32) == tag && (unsigned int)(b[j] >> 32) == tag;
+    if (__all(all)) break;
+    if ((++spins & 63u) == 0u && __any((unsigned long long)(wall_clock64() - t0) > limit)) {
+      ok = false;
+      break;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int i = r + 8 * j;
+    if (active && i < cnt)
+      s += __longlong_as_double((long long)(((unsigned long long)(unsigned int)b[j] << 32) | (unsigned int)a[j]));
+  }
+  s += __shfl_xor(s, 4);
+  s += __shfl_xor(s, 2);
+  s += __shfl_xor(s, 1);
+  return s;
+}
+
+// Cheap first wait of a summing workgroup: thread i < cnt watches ONE granule of row i (the last one written) - a
+// sweep is cnt loads, not cnt * 2 NS - and the full batches of poll_column_sum only start when every row has shown up
+// (their own tag checks still decide: a row's stores may land in any order).
+__device__ __forceinline__ void wait_rows(const unsigned long long *base, int cnt, int last_granule, unsigned int tag,
+                                          unsigned long long limit) {
+  if ((int)threadIdx.x < cnt) {
+    const unsigned long long *src = base + (size_t)threadIdx.x * kLoopRow + last_granule;
+    const long long t0 = wall_clock64();
+    unsigned int spins = 0;
+    while ((unsigned int)(ld_granule(src) >> 32) != tag) {
+      if ((++spins & 63u) == 0u && (unsigned long long)(wall_clock64() - t0) > limit) break;  // poll_column_sum reports
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  __syncthreads();
+}
+
+// The solve as a function of its own: inlined into the loop kernel its matrices share the 64 registers with whatever
+// the register allocator keeps alive across the iterations, and the polar iteration ran out of scratch memory
+template <int EST>
+__device__ __attribute__((noinline)) void loop_solve(const double *fin, IcpDevState *st, double *work, const SolveIn *in) {
+  icp_solve_body<EST>(fin, st, work, in);
+}
+
+// Returns true when the launch goes on with another iteration (T = the transform to apply in it).
+template <int EST>
+__device__ __forceinline__ bool icp_loop_tail(const IcpTail &tail, double (*lds)[SumsOf<EST>::n], unsigned int tag,
+                                              Xf &T) {
+  constexpr int NS = SumsOf<EST>::n;
+  static_assert(2 * NS <= kLoopRow, "row too short");
+  __shared__ double fin[NS];
+  __shared__ double svd_work[42];
+  __shared__ SolveIn sin;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int nblk = gridDim.x;
+  unsigned long long *rows = tail.loopbox;                                 // [nblk][kLoopRow]
+  unsigned long long *grows = rows + (size_t)nblk * kLoopRow;              // [ngroups][kLoopRow]
+  unsigned long long *pub = grows + (size_t)tail.ngroups * kLoopRow;       // [kLoopRow]
+  const unsigned long long tg = (unsigned long long)tag << 32;
+  const unsigned long long limit =
+      tail.comm.timeout_ticks > 250000000ull ? 2ull * tail.comm.timeout_ticks : 500000000ull;  // >= 5 s
+  if (tid < NS) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < ICP_WPB; ++w) s += lds[w][tid];
+    put_granules(rows + (size_t)blockIdx.x * kLoopRow + 2 * tid, s, tg);
+  }
+  const int g = blockIdx.x / ICP_GROUP;
+  const int r = tid & 7;
+  bool ok = true;
+  if (blockIdx.x % ICP_GROUP == 0) {  // the group's first workgroup adds up the group
+    const int gsize = min(ICP_GROUP, nblk - g * ICP_GROUP);
+    wait_rows(rows + (size_t)g * ICP_GROUP * kLoopRow, gsize, 2 * NS - 1, tag, limit);
+#pragma unroll
+    for (int c0 = 0; c0 < NS; c0 += 32) {
+      const int col = c0 + (tid >> 3);
+      const bool colth = col < NS;
+      const double s = poll_column_sum(rows + (size_t)g * ICP_GROUP * kLoopRow + 2 * (colth ? col : 0), gsize, r, colth,
+                                       tag, limit, ok);
+      if (colth && r == 0) {
+        // one group: its sum goes through the second level's additions (s + 0 + 0 + 0) without the trip through memory
+        if (tail.ngroups == 1) fin[col] = ((s + 0.0) + 0.0) + 0.0;
+        else put_granules(grows + (size_t)g * kLoopRow + 2 * col, s, tg);
+      }
+    }
+  }
+  if (blockIdx.x == 0) {
+    if (tail.ngroups > 1) {
+      wait_rows(grows, tail.ngroups, 2 * NS - 1, tag, limit);
+#pragma unroll
+      for (int c0 = 0; c0 < NS; c0 += 32) {
+        const int col = c0 + (tid >> 3);
+        const bool colth = col < NS;
+        const double s = poll_column_sum(grows + 2 * (colth ? col : 0), tail.ngroups, r, colth, tag, limit, ok);
+        if (colth && r == 0) fin[col] = s;
+      }
+    }
+    const bool failed = __syncthreads_or(ok ? 0 : 1) != 0;
+    if (tid < 64) {
+      IcpDevState *st = tail.st;
+      const unsigned long long tk1 = (unsigned long long)wall_clock64();
+      fetch_solve_in<true>(st, &sin, lane);  // workgroup 0 wrote these itself in the last iteration
+      double v = lane < NS ? fin[lane] : 0.0;
+      bool good = !failed;
+      int status = failed ? PCLMI_ERR_HIP : PCLMI_OK;
+      if (good && tail.comm.world > 1) {
+        const unsigned int seq = ld_state<true>(tail.comm.seq) + 1u;
+        good = comm_allreduce_wave(tail.comm, v, NS, lane, seq);
+        if (lane == 0) st_state<true>(tail.comm.seq, seq);
+        if (!good) status = PCLMI_ERR_COMM;
+      }
+      if (lane < NS) {
+        tail.sums_out[lane] = v;
+        fin[lane] = v;
+      }
+      if (lane == 0) {
+        st->ticks[1] = tk1;
+        st->ticks[2] = (unsigned long long)wall_clock64();
+        st->apply = 0;  // this iteration has consumed the pending transform
+        if (!good) {
+          st->status = status;
+          st->done = 1;
+        } else {
+          loop_solve<EST>(fin, st, svd_work, &sin);
+          st->last_inliers = st->last_pairs;
+        }
+        st->ticket = tag;
+        st->ticks[3] = (unsigned long long)wall_clock64();
+      }
+      // publish: lanes 0-11 the transform's three rows, lane 12 the stop flag (lane 0's stores above are this
+      // wavefront's own: ordered before these loads)
+      __builtin_amdgcn_s_waitcnt(0);
+      __builtin_amdgcn_wave_barrier();
+      unsigned int word = 0;
+      if (lane < 12) word = __float_as_uint(ld_state<true>(&st->T[lane]));
+      else if (lane == 12) word = (unsigned int)ld_state<true>(&st->done);
+      if (lane < 13) __hip_atomic_store((gl_u64p)(pub + lane), tg | word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  // wait for the publication: the workgroup's LAST wavefront polls (the first one of workgroup 0 is the publisher)
+  // and hands the words to the others through LDS - a quarter of the polling traffic of every wavefront for itself
+  __shared__ unsigned int s_pub[16];
+  if (tid >= 64 * (ICP_WPB - 1)) {
+    unsigned long long w = tg;
+    const long long t0 = wall_clock64();
+    unsigned int spins = 0;
+    bool seen = true;
+    for (;;) {
+      if (lane < 13) w = ld_granule(pub + lane);
+      if (__all((unsigned int)(w >> 32) == tag)) break;
+      if ((++spins & 63u) == 0u && __any((unsigned long long)(wall_clock64() - t0) > 2ull * limit)) {
+        seen = false;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    if (lane < 13) s_pub[lane] = (unsigned int)w;
+    if (lane == 13) s_pub[13] = seen ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_pub[13]) return false;
+#pragma unroll
+  for (int j = 0; j < 12; ++j) T.m[j] = __uint_as_float(s_pub[j]);
+  const bool go_on = s_pub[12] == 0u;
+  __syncthreads();  // s_pub is read before the next iteration's polling wave overwrites it
+  return go_on;
+}
+
 // One ICP iteration over the (Morton-ordered) source points.  See file header.
 // LANE: per-lane traversal (traverse.hpp lane_nearest) with `levels` rows of LDS per wave, started from the
 // distance to the previous step's neighbour (nn_slot, when have_prev) below the wave's common subtree;
@@ -431,8 +664,12 @@ __device__ __forceinline__ void icp_step_tail(const IcpTail &tail, double *__res
 // lane has just found), src_skip (nullable) flags source points whose own normal is not finite (:158-174 skips them).
 // RS: the step of the RANSAC loop (pclmi_icp_align with ransac_iterations > 0): also leaves keep_slot[slot] = "this
 // point has a pair" for the passes of the rejection step and adds the paired source points' second moments.
-template <bool LANE, int EST, bool RS, bool SC>
-__global__ __launch_bounds__(64 * ICP_WPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void icp_step_kernel(TreeView t, float4 *__restrict__ pts, int n,
+// LOOP: the RESIDENT loop - up to loop_iters iterations in ONE launch (see icp_loop_tail): a shard of <= ~0.25M points
+// pays no launch boundary (8-15 us) per iteration.  The host checks the grid against the occupancy (icp_loop_fits);
+// with every workgroup resident the occupancy that hides the walk's latency elsewhere is not needed: 128 registers, no
+// spills on the walk and in the solve.
+template <bool LANE, int EST, bool RS, bool SC, bool LOOP>
+__global__ __launch_bounds__(64 * ICP_WPB) __attribute__((amdgpu_waves_per_eu(LOOP ? 4 : 8, LOOP ? 4 : 8))) void icp_step_kernel(TreeView t, float4 *__restrict__ pts, int n,
                                                                  int apply, Xf T, float thr2f, double thr2,
                                                                  int *__restrict__ nn_idx, int *__restrict__ nn_slot,
                                                                  float *__restrict__ dist, double ox, double oy,
@@ -444,9 +681,10 @@ __global__ __launch_bounds__(64 * ICP_WPB) __attribute__((amdgpu_waves_per_eu(8,
                                                                  unsigned char *__restrict__ keep_slot,
                                                                  float4 *__restrict__ tq,
                                                                  const float4 *__restrict__ raw_tgt, float ax, float ay,
-                                                                 float az) {
+                                                                 float az, int loop_iters) {
   static_assert(LANE || !EST, "the point-to-plane loop reads the target normals by bucket slot");
   static_assert(!SC || !EST, "the rescaled search is the SVD estimator's");
+  static_assert(!LOOP || (LANE && !RS && !SC), "the resident loop: per-lane walk, no RANSAC step, no rescaled search");
   extern __shared__ float far_lds[];
   __shared__ double lds[ICP_WPB][SumsOf<EST, RS>::n];
   if (st) {  // device-resident loop: the pending transform and the stop flag live in device memory
@@ -455,7 +693,19 @@ __global__ __launch_bounds__(64 * ICP_WPB) __attribute__((amdgpu_waves_per_eu(8,
 #pragma unroll
     for (int j = 0; j < 12; ++j) T.m[j] = st->T[j];
   }
-  if (tail.st && blockIdx.x == 0 && threadIdx.x == 0) tail.st->ticks[0] = (unsigned long long)wall_clock64();
+  // LOOP: iterations completed when this launch began (written by an earlier launch: every workgroup reads the same)
+  const unsigned int epoch0 = LOOP ? st->ticket : 0u;
+  for (int it = 0; it < (LOOP ? loop_iters : 1); ++it) {
+  if (LOOP && it > 0) {
+    apply = 1;
+    have_prev = 1;
+  }
+  if (tail.st && blockIdx.x == 0 && threadIdx.x == 0) {
+    tail.st->ticks[0] = (unsigned long long)wall_clock64();
+#ifdef PCLMI_LOOP_TICKS
+    tail.st->walk[it & 7] = tail.st->ticks[0];
+#endif
+  }
 #ifdef PCLMI_ICP_TICKS
   const bool stamp = tail.st && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0;
 #define PCLMI_WALK_STAMP(i)                                                   \
@@ -596,7 +846,11 @@ __global__ __launch_bounds__(64 * ICP_WPB) __attribute__((amdgpu_waves_per_eu(8,
       wave_reduce_to_row(v, paired, &lds[wib][32], lane);
     }
     __syncthreads();
-    icp_step_tail<1, RS>(tail, partials, lds);
+    if constexpr (LOOP) {
+      if (!icp_loop_tail<1>(tail, lds, epoch0 + (unsigned int)it + 1u, T)) return;
+    } else {
+      icp_step_tail<1, RS>(tail, partials, lds);
+    }
   } else {
   // fp64 moments, reduced in three groups of eight so that at most 16 accumulator registers are live at a
   // time (the register budget is 64 VGPRs = 8 waves per SIMD: the search is latency-bound)
@@ -620,8 +874,13 @@ __global__ __launch_bounds__(64 * ICP_WPB) __attribute__((amdgpu_waves_per_eu(8,
     wave_reduce_to_row(v, paired, &lds[wib][24], lane);
   }
   __syncthreads();
-  icp_step_tail<0, RS>(tail, partials, lds);
+  if constexpr (LOOP) {
+    if (!icp_loop_tail<0>(tail, lds, epoch0 + (unsigned int)it + 1u, T)) return;
+  } else {
+    icp_step_tail<0, RS>(tail, partials, lds);
   }
+  }
+  }  // iterations of the launch
 }
 
 // fixed-order sum of one column of block partials by one workgroup of 256: element r of column j sits at
@@ -2023,13 +2282,47 @@ unsigned icp_step_blocks(size_t n) {
   return blocks ? blocks : 8u;  // an empty shard still launches: its sums are zeros, its tail runs the exchange
 }
 
+// Can every workgroup of a step launch over n points be resident at once (the resident loop's precondition)?
+bool icp_loop_fits(const pclmi_tree *t, size_t n, bool plane) {
+  if (!(plane || nn1_per_lane())) return false;
+  static const bool off = [] { const char *e = getenv("PCLMI_ICP_LOOP"); return e && e[0] == '0'; }();
+  if (off) return false;
+  const int levels = lane_nearest_levels(t->M);
+  const size_t lds_bytes = (size_t)ICP_WPB * levels * 64 * sizeof(float);
+  int per_cu = 0, dev = 0;
+  hipError_t e = plane ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, icp_step_kernel<true, 1, false, false, true>,
+                                                                      64 * ICP_WPB, lds_bytes)
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, icp_step_kernel<true, 0, false, false, true>,
+                                                                      64 * ICP_WPB, lds_bytes);
+  hipDeviceProp_t prop;
+  if (e != hipSuccess || hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  // PCLMI_DEVICE_SHARE = n: n ranks of one job run on this GPU (rehearsals of the sharded loop on one device): their
+  // resident loops wait for each other's sums, so all of them must fit on the chip together
+  static const int share = [] { const char *e = getenv("PCLMI_DEVICE_SHARE"); const int v = e ? atoi(e) : 1; return v > 1 ? v : 1; }();
+  return (size_t)icp_step_blocks(n) * (size_t)share <= (size_t)per_cu * (size_t)prop.multiProcessorCount;
+}
+size_t icp_loop_box_words(size_t n) { return ((size_t)icp_step_blocks(n) + icp_step_groups(n) + 1) * kLoopRow; }
+
+#ifdef PCLMI_WALK_COUNT
+}  // namespace pclmi
+// development aid: [0] max outer rounds of a wave's walk, [1] max descend steps, [2] sum of rounds, [3] waves
+extern "C" int pclmi_debug_walk_count(unsigned int out[4]) {
+  unsigned int z[4] = {0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pclmi::dev::g_walk_count), sizeof(z)) != hipSuccess) return 1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(pclmi::dev::g_walk_count), z, sizeof(z)) != hipSuccess;
+}
+namespace pclmi {
+#endif
 unsigned icp_step_groups(size_t n) { return (icp_step_blocks(n) + ICP_GROUP - 1) / ICP_GROUP; }
 
 void launch_icp_step(const pclmi_tree *t, float4 *d_pts, size_t n, bool apply, const Xf &T, double thr2,
                      int *d_nn, int *d_nn_slot, float *d_dist, const double origin[3], double *d_partials,
                      hipStream_t s, IcpDevState *st, bool have_prev, const IcpTail &tail, const float4 *d_tn_slot,
                      const unsigned char *d_src_skip, unsigned char *d_keep_slot, float4 *d_tq, const float4 *d_raw_tgt,
-                     const float *scale) {
+                     const float *scale, int loop_iters) {
   const float sc[3] = {scale ? scale[0] : 1.f, scale ? scale[1] : 1.f, scale ? scale[2] : 1.f};
   const unsigned blocks = icp_step_blocks(n);
   const bool plane = d_tn_slot != nullptr;  // the point-to-plane loop always walks per lane
@@ -2038,13 +2331,16 @@ void launch_icp_step(const pclmi_tree *t, float4 *d_pts, size_t n, bool apply, c
   TimingScope ts(PCLMI_TIMER_ICP_STEP, s);
   const size_t lds_bytes = (size_t)ICP_WPB * levels * 64 * sizeof(float);
   const bool scl = d_raw_tgt != nullptr;    // searches in a rescaled space (api_icp.hip refuses it with the plane loop)
-#define PCLMI_STEP_LAUNCH(LANE_, EST_, RS_, SC_, LDS_)                                                                      \
-  hipLaunchKernelGGL((icp_step_kernel<LANE_, EST_, RS_, SC_>), dim3(blocks), dim3(64 * ICP_WPB), LDS_, s, t->view(), d_pts, \
+  const bool loop = loop_iters > 1;  // the caller has checked icp_loop_fits() and set tail.loopbox
+#define PCLMI_STEP_LAUNCH(LANE_, EST_, RS_, SC_, LDS_) PCLMI_STEP_LAUNCH5(LANE_, EST_, RS_, SC_, false, LDS_)
+#define PCLMI_STEP_LAUNCH5(LANE_, EST_, RS_, SC_, LOOP_, LDS_)                                                              \
+  hipLaunchKernelGGL((icp_step_kernel<LANE_, EST_, RS_, SC_, LOOP_>), dim3(blocks), dim3(64 * ICP_WPB), LDS_, s, t->view(), d_pts, \
                      (int)n, apply ? 1 : 0, T, (float)thr2, thr2, d_nn, d_nn_slot, d_dist, origin[0], origin[1],        \
                      origin[2], d_partials, (const IcpDevState *)st, levels, have_prev ? 1 : 0, tail, d_tn_slot,        \
-                     d_src_skip, d_keep_slot, d_tq, d_raw_tgt, sc[0], sc[1], sc[2])
+                     d_src_skip, d_keep_slot, d_tq, d_raw_tgt, sc[0], sc[1], sc[2], loop_iters)
   if (plane) {
     if (rsv) PCLMI_STEP_LAUNCH(true, 1, true, false, lds_bytes);
+    else if (loop) PCLMI_STEP_LAUNCH5(true, 1, false, false, true, lds_bytes);
     else PCLMI_STEP_LAUNCH(true, 1, false, false, lds_bytes);
   } else if (levels > 0) {
     if (scl) {
@@ -2052,6 +2348,7 @@ void launch_icp_step(const pclmi_tree *t, float4 *d_pts, size_t n, bool apply, c
       else PCLMI_STEP_LAUNCH(true, 0, false, true, lds_bytes);
     } else {
       if (rsv) PCLMI_STEP_LAUNCH(true, 0, true, false, lds_bytes);
+      else if (loop) PCLMI_STEP_LAUNCH5(true, 0, false, false, true, lds_bytes);
       else PCLMI_STEP_LAUNCH(true, 0, false, false, lds_bytes);
     }
   } else {
@@ -2064,6 +2361,7 @@ void launch_icp_step(const pclmi_tree *t, float4 *d_pts, size_t n, bool apply, c
     }
   }
 #undef PCLMI_STEP_LAUNCH
+#undef PCLMI_STEP_LAUNCH5
 }
 
 unsigned pair_reduce_blocks(size_t n) {

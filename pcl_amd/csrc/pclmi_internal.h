@@ -293,6 +293,8 @@ struct IcpTail {
   struct RansacLoopState *rl = nullptr;
   const struct RansacTrial *trials = nullptr;
   int max_trials = 0;
+  // the resident loop (icp_step_kernel<.., LOOP>): rows of tagged granules - block sums, group sums, the publication
+  unsigned long long *loopbox = nullptr;
   CommView comm;
 };
 constexpr int kIcpMaxSums = PCLMI_ICP_NSUMS_PLANE + 8;  // the point-to-plane step of the RANSAC loop
@@ -319,7 +321,11 @@ void launch_icp_step(const pclmi_tree *t, float4 *d_pts, size_t n, bool apply, c
                      float4 *d_tq = nullptr /* with d_keep_slot: the matched target point per slot */,
                      const float4 *d_raw_tgt = nullptr /* non-null: the tree indexes scale * point (a rescaling point
                                                            representation); the estimator reads these rows */,
-                     const float *scale = nullptr);
+                     const float *scale = nullptr,
+                     int loop_iters = 1 /* > 1: the resident loop, up to that many iterations in this ONE launch (needs
+                                           st, tail.solve, icp_loop_fits(); not with d_keep_slot / d_raw_tgt) */);
+bool icp_loop_fits(const pclmi_tree *t, size_t n, bool plane);
+size_t icp_loop_box_words(size_t n);  // 8-byte words of IcpTail::loopbox for a shard of n points
 // point-to-plane loop (d_tn_slot != nullptr above): PCLMI_ICP_NSUMS_PLANE sums per launch
 void launch_pair_reduce_plane(const float4 *src, const int *sidx, const float4 *tgt, const int *tidx, const float4 *tn,
                               const unsigned char *src_skip, const unsigned char *flags, size_t n, double *d_partials,

@@ -140,13 +140,21 @@ PCLMI_HD double det3(const double M[9]) {
 // far inside the fp32 rounding of T.  Returns false (caller takes the SVD path, which also handles the reflection
 // fix of transformation_estimation_svd.hpp:156-160 and rank-deficient H) when the normalised determinant is not
 // safely positive.  Only IEEE +,-,*,/,sqrt: same bits on host and device.
+//
+// What has to be exact and what does not: X <- a X + b cof(X) maps U diag(s) V' to U diag(a s + b det / s) V' for ANY
+// scalars a, b - the singular VECTORS (the answer) are untouched, only the path of the singular values to 1 depends
+// on them.  So the normalisation of X0 and the scaling factors of the first steps are computed in fp32 (correctly
+// rounded / and sqrt on both sides: still the same bits on host and device) - an fp64 division or square root is ~200
+// cycles of dependent latency for the one lane that solves, and the scaled steps had five of them each; the plain steps
+// at the end (a = 1/2, b = 1/(2 det): the fixed point must be the ORTHOGONAL factor) keep their fp64 division.
 PCLMI_HD bool polar_rotation(const double H[9], double R[9]) {
   double f2 = 0.0;
 #pragma unroll
   for (int i = 0; i < 9; ++i) f2 += H[i] * H[i];
   if (!(f2 > 0.0)) return false;
-  const double inv_f = 1.0 / sqrt(f2);
-  double X[9];  // X0 = H' / ||H||_F
+  // ~1 / ||H||_F: a power-of-two-exact fp64 product of the fp32 estimate (any positive factor would do)
+  const double inv_f = f2 > 1e-60 && f2 < 1e60 ? (double)(1.0f / sqrtf((float)f2)) : 1.0 / sqrt(f2);
+  double X[9];  // X0 = H' / ~||H||_F
 #pragma unroll
   for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -166,7 +174,8 @@ PCLMI_HD bool polar_rotation(const double H[9], double R[9]) {
     const double det = X[0] * C[0] + X[1] * C[1] + X[2] * C[2];
     if (it == 0 && !(det > 1e-9)) return false;  // singular values s1 s2 s3 / ||H||^3: reflection or near-singular
     if (!(det > 0.0)) return false;
-    double a = 0.5, b = 0.5 / det;  // X <- a X + b C
+    double a, b;  // X <- a X + b C
+    bool plain = !scaled;
     if (scaled) {  // g = sqrt(||X^-T||_F / ||X||_F): brings the singular values to 1 from both sides
       double nx = 0.0, nc = 0.0;
 #pragma unroll
@@ -174,10 +183,21 @@ PCLMI_HD bool polar_rotation(const double H[9], double R[9]) {
         nx += X[i] * X[i];
         nc += C[i] * C[i];
       }
-      const double g2 = sqrt(nc / nx) / det;  // g^2
-      const double g = sqrt(g2);
-      a = 0.5 * g;
-      b = 0.5 / (g * det);
+      const float detf = (float)det;
+      const float g2 = sqrtf((float)nc / (float)nx) / detf;  // g^2
+      const float g = sqrtf(g2);
+      const float bf = 0.5f / (g * detf);
+      // out of fp32's comfortable range (or not finite): the plain step
+      if (g > 1e-18f && g < 1e18f && bf > 1e-30f && bf < 1e30f) {
+        a = 0.5 * (double)g;
+        b = (double)bf;
+      } else {
+        plain = true;
+      }
+    }
+    if (plain) {
+      a = 0.5;
+      b = 0.5 / det;
     }
     double d2 = 0.0;
 #pragma unroll
@@ -188,7 +208,9 @@ PCLMI_HD bool polar_rotation(const double H[9], double R[9]) {
       X[i] = xn;
     }
     if (d2 < 1e-4) scaled = false;  // close to orthogonal: the plain iteration converges quadratically from here
-    if (d2 < 1e-20) break;          // ||step|| < 1e-10: what is left after this step is ~1e-20, below fp64 resolution
+    // ||step|| < 1e-10 after a PLAIN step: what is left is ~1e-20, below fp64 resolution (a scaled step's factors are
+    // fp32: it may land 1e-7 from orthogonal, and says nothing about the error)
+    if (plain && d2 < 1e-20) break;
   }
 #pragma unroll
   for (int i = 0; i < 9; ++i) R[i] = X[i];
@@ -268,40 +290,57 @@ PCLMI_HD void svd_rotation(const double H[9], double R[9], double *work) {
 
 // sums layout: pclmi.h (PCLMI_ICP_NSUMS).  Returns false (T = identity) when there is no pair.
 PCLMI_HD bool solve_from_sums(const double *sums, float T[16], double *work /* 42 doubles, see svd3 */) {
-#pragma unroll
-  for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.f : 0.f;
   const double n = sums[0];
-  if (!(n >= 1.0)) return false;
-  double o[3] = {0, 0, 0};
-  if (sums[18] > 0.0) {
+  if (!(n >= 1.0)) {
 #pragma unroll
-    for (int d = 0; d < 3; ++d) o[d] = sums[19 + d] / sums[18];
+    for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.f : 0.f;
+    return false;
   }
-  double ms[3], mt[3];  // centroids relative to the origin
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    ms[d] = sums[1 + d] / n;
-    mt[d] = sums[4 + d] / n;
-  }
+  // one reciprocal per divisor (an fp64 division is ~200 cycles of one lane's dependent latency, this runs on the
+  // critical path of every ICP iteration; the last-bit difference to nine divisions is far inside T's fp32 rounding)
+  const double inv_n = 1.0 / n;
+  const double inv_c = sums[18] > 0.0 ? 1.0 / sums[18] : 0.0;
   double H[9];
+  {
+    double ms[3], mt[3];  // centroids relative to the origin
 #pragma unroll
-  for (int r = 0; r < 3; ++r)
+    for (int d = 0; d < 3; ++d) {
+      ms[d] = sums[1 + d] * inv_n;
+      mt[d] = sums[4 + d] * inv_n;
+    }
 #pragma unroll
-    for (int c = 0; c < 3; ++c) H[r * 3 + c] = sums[7 + r * 3 + c] - n * ms[r] * mt[c];
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) H[r * 3 + c] = sums[7 + r * 3 + c] - n * ms[r] * mt[c];
+    // parked in `work` (LDS on the GPU) while the rotation is computed: nothing but the iteration's matrices is live
+    // in registers then (the step kernel's budget is 64 VGPRs; what does not fit goes to scratch memory)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      work[33 + d] = ms[d] + sums[19 + d] * inv_c;  // source centroid
+      work[36 + d] = mt[d] + sums[19 + d] * inv_c;  // target centroid
+    }
+  }
   double R[9];
   if (!polar_rotation(H, R)) {
     double Hc[9];
-    if (!(rank2_completion(H, Hc) && polar_rotation(Hc, R))) svd_rotation(H, R, work);
+    if (!(rank2_completion(H, Hc) && polar_rotation(Hc, R))) {
+      const double keep[6] = {work[33], work[34], work[35], work[36], work[37], work[38]};
+      svd_rotation(H, R, work);
+#pragma unroll
+      for (int d = 0; d < 6; ++d) work[33 + d] = keep[d];
+    }
   }
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     double rc = 0;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) rc += R[r * 3 + c] * (ms[c] + o[c]);
+    for (int c = 0; c < 3; ++c) rc += R[r * 3 + c] * work[33 + c];
 #pragma unroll
     for (int c = 0; c < 3; ++c) T[r * 4 + c] = (float)R[r * 3 + c];
-    T[r * 4 + 3] = (float)((mt[r] + o[r]) - rc);  // t = ct - R cs
+    T[r * 4 + 3] = (float)(work[36 + r] - rc);  // t = ct - R cs
   }
+  T[12] = T[13] = T[14] = 0.f;
+  T[15] = 1.f;
   return true;
 }
 

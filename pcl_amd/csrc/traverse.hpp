@@ -469,6 +469,9 @@ __device__ __forceinline__ int wave_common_root(const TreeView &t, float qx, flo
 // whole wave converged (the k-NN kernel compacts its candidate buffer there).
 // start: the node a lane's walk begins at - `root`, or (lane_start_at_leaf) a bucket below it whose path up to the
 // root has its far[] entries filled in already.
+#ifdef PCLMI_WALK_COUNT
+__device__ unsigned int g_walk_count[4];  // [0] outer rounds, [1] descend steps, [2] leaf scans, [3] start-at-leaf steps: maxima
+#endif
 template <class LeafFn, class RoundFn>
 __device__ __forceinline__ void lane_traverse(const TreeView &t, float qx, float qy, float qz, bool searchable,
                                               float tau, float (*far)[64], int lane, int root, LeafFn leaf,
@@ -478,10 +481,19 @@ __device__ __forceinline__ void lane_traverse(const TreeView &t, float qx, float
   unsigned int trail = 0;  // bit l set: the node on the current path at level l is the second child visited
   bool active = searchable;
   const f2v q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
+#ifdef PCLMI_WALK_COUNT
+  unsigned int n_round = 0, n_desc = 0;
+#endif
   while (__any(active)) {
+#ifdef PCLMI_WALK_COUNT
+    ++n_round;
+#endif
     // ---- descend towards the nearer child while the subtree can still hold something <= tau
     bool pruned = false;
     while (__any(active && !pruned && node < M)) {
+#ifdef PCLMI_WALK_COUNT
+      ++n_desc;
+#endif
       if (active && !pruned && node < M) {
         if (2 * node + 1 < M) {
           // two levels per step (half as many dependent loads): the four grandchildren boxes; a child's
@@ -550,6 +562,14 @@ __device__ __forceinline__ void lane_traverse(const TreeView &t, float qx, float
       }
     }
   }
+#ifdef PCLMI_WALK_COUNT
+  if (lane == 0) {
+    atomicMax(&g_walk_count[0], n_round);
+    atomicMax(&g_walk_count[1], n_desc);
+    atomicAdd(&g_walk_count[2], n_round);
+    atomicAdd(&g_walk_count[3], 1u);
+  }
+#endif
 }
 
 // Bottom-up start of a per-lane walk: the lane already knows a bucket that very likely holds its answer (ICP: the

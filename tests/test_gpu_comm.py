@@ -22,7 +22,7 @@ def test_two_process_allreduce_and_sharded_icp(tmp_path):
     from tests import comm_worker
     assert capi.device_count() > 0, "no HIP device: the GPU tests must run on the MI355X box"
     name = "t%s" % uuid.uuid4().hex[:12]
-    env = dict(os.environ, PYTHONPATH=str(ROOT))
+    env = dict(os.environ, PYTHONPATH=str(ROOT), PCLMI_DEVICE_SHARE="2")  # the ranks share one GPU here
     procs = [subprocess.Popen([sys.executable, "-u", str(ROOT / "tests" / "comm_worker.py"), str(r), "2", name,
                                str(tmp_path / ("r%d.npz" % r))], env=env, cwd=str(ROOT),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]

@@ -340,6 +340,62 @@ def test_device_resident_loop_equals_host_driven_loop(capi, orc):
     ctx.end(want_aligned=False)
 
 
+@pytest.mark.parametrize("plane", [False, True])
+def test_resident_loop_equals_one_launch_per_iteration(capi, orc, plane):
+    """pclmi_icp_run_dev with several iterations on a shard whose workgroups are all resident at once runs them inside
+    ONE launch (the workgroups wait for the solve between iterations); one iteration per call is one launch each.
+    Same arithmetic in the same order: state, pairs and the moved cloud are equal bit for bit; the criteria stop the
+    launch from inside."""
+    tgt = surface_cloud(60000, 171)
+    T0 = rigid(1.5, (1, 0, 1), (0.3, 0.1, -0.2))
+    src = orc.transform(tgt[::2] + np.float32(0.01), np.linalg.inv(T0))
+    tt = capi.Tree(tgt)
+    tn = capi.normals(tt, tgt, k=12)[:, :3].copy() if plane else None
+
+    def begin():
+        c = capi.IcpShard(tt, src)
+        if plane:
+            c.set_point_to_plane(tn)
+        return c
+    a, b = begin(), begin()
+    a.run_dev(2.0, 9)
+    for _ in range(9):
+        b.run_dev(2.0, 1)
+    rca, Ta, sta = a.state()
+    rcb, Tb, stb = b.state()
+    assert rca == rcb == 0 and sta.iterations == stb.iterations == 9
+    assert sta.last_correspondences == stb.last_correspondences and sta.fitness_delta == stb.fitness_delta
+    assert np.array_equal(Ta, Tb) and np.array_equal(np.asarray(sta.last_transform), np.asarray(stb.last_transform))
+    a.run_dev(2.0, 3)   # a second resident launch carries on from the first
+    b.run_dev(2.0, 3)   # (3 per-iteration launches, or one resident launch - either way the same state)
+    rca, Ta, sta = a.state()
+    rcb, Tb, stb = b.state()
+    assert sta.iterations == stb.iterations == 12 and np.array_equal(Ta, Tb)
+    assert np.array_equal(a.end(), b.end())
+    # criteria: the launch ends itself at max_iterations / the epsilon, later launches are no-ops
+    p = capi.icp_default_params()
+    p.ransac_iterations, p.max_iterations, p.transformation_epsilon = 0, 40, 1e-6
+    a, b = begin(), begin()
+    a.set_criteria(p)
+    b.set_criteria(p)
+    a.run_dev(2.0, 64)
+    for _ in range(45):
+        b.run_dev(2.0, 1)
+    a.run_dev(2.0, 5)
+    rca, Ta, sta = a.state()
+    rcb, Tb, stb = b.state()
+    assert sta.converged and stb.converged and sta.iterations == stb.iterations < 40
+    assert np.array_equal(Ta, Tb) and np.array_equal(a.end(), b.end())
+    # not enough correspondences inside a resident launch
+    c = capi.IcpShard(tt, src + np.float32(1e4))
+    p.max_correspondence_distance = 1.0
+    c.set_criteria(p)
+    c.run_dev(1.0, 6)
+    rc, T, st = c.state()
+    assert rc == 6 and st.iterations == 0
+    c.end(want_aligned=False)
+
+
 def test_rccl_all_reduce_between_the_library_kernels():
     """tests/rccl_single_rank.py in a process of its own: a one-rank nccl (= RCCL) process group, the sharded
     device-resident driver and bench.py's N > 1 loop shape with the all-reduce issued between the library's step and
