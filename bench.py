@@ -646,12 +646,31 @@ def bench_extras(env, tree, target, q_host, q_dev, stream):
         for i in range(2000):
             lib.pclmi_knn(tree.h, one[i].ctypes.data, 1, 12, K, oi1.ctypes.data, od1.ctypes.data, C.byref(ke))
         single_us = (time.perf_counter() - t0) / 2000 * 1e6
+        off1 = np.zeros(2, np.uint64)
+        rpi, rpd = C.c_void_p(), C.c_void_p()
+
+        def radius_one(i):
+            rc = lib.pclmi_radius(tree.h, one[i].ctypes.data, 1, 12, r, 0, 1, off1.ctypes.data, C.byref(rpi), C.byref(rpd))
+            assert rc == 0, lib.pclmi_last_error()
+            lib.pclmi_free(rpi)
+            lib.pclmi_free(rpd)
+        for i in range(200):
+            radius_one(i)
+        t0 = time.perf_counter()
+        for i in range(2000):
+            radius_one(i)
+        radius_single_us = (time.perf_counter() - t0) / 2000 * 1e6
         ex["host_pointer_path"] = {"knn_pcie_inclusive_qps": pcie,
                                    "knn_pcie_inclusive_note": "pclmi_knn, 1M queries, k = 16, pageable host buffers: "
                                                               "16 MB up + 128 MB down per call",
                                    "knn_single_query_us": single_us,
                                    "knn_single_query_note": "pclmi_knn with nq = 1 (what pcl::KdTreeFLANN::"
-                                                            "nearestKSearch calls), k = 16, through ctypes"}
+                                                            "nearestKSearch calls), k = 16, through ctypes",
+                                   "radius_single_query_us": radius_single_us,
+                                   "radius_single_query_note": "pclmi_radius with nq = 1 (pcl::KdTreeFLANN::"
+                                                               "radiusSearch), configs[2]'s radius (~31 neighbours), "
+                                                               "sorted: two launches and one wait, results through "
+                                                               "pinned host memory"}
     if world == 1:
         # ---- ICP with the reference's default RANSAC rejection step (icp.h:104: 1000 trials): device-resident loop
         #      (step, draw, count + refit + stopping rule + solve kernels; the host feeds further batches of trials

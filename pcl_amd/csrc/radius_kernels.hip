@@ -910,6 +910,104 @@ int radius_search_dev(const pclmi_tree *t, Workspace *w, const float *d_q, size_
   return PCLMI_OK;
 }
 
+// ---- a few queries from the host (pcl::KdTreeFLANN::radiusSearch, one point per call) --------------------------
+// The general path above is built for batches: ordering pass, count scan, totals read back, output arrays from the
+// cache, three downloads - a dozen enqueues and two host waits, 133 us for one query.  Up to kSmallRadiusQueries
+// queries take two launches and ONE wait instead: the per-lane traversal leaves every query's first PROV_CAP keys in a
+// fixed-pitch row (device memory) and its count in the slot's pinned host buffer; one wavefront per query then sorts
+// the row and writes idx / d2 rows into the pinned buffer in place.  The host builds the CSR arrays from there.  A
+// query with more than PROV_CAP neighbours sends the call to the general path.
+constexpr size_t kSmallRadiusQueries = 64;
+__global__ __launch_bounds__(64) void small_rows_sort_kernel(const u64 *__restrict__ prov,
+                                                             const unsigned int *__restrict__ counts, int nq,
+                                                             int by_index, int *__restrict__ idx_rows,
+                                                             float *__restrict__ d2_rows) {
+  const int qi = blockIdx.x, lane = threadIdx.x;
+  if (qi >= nq) return;
+  const int ln = (int)counts[qi];
+  if (ln == 0 || ln > PROV_CAP) return;  // (too long: the host takes the general path)
+  u64 k = lane < ln ? prov[(size_t)qi * PROV_CAP + lane] : ~0ull;
+  if (ln > 32) k = wave_bitonic<64>(k, lane);
+  else if (ln > 16) k = wave_bitonic<32>(k, lane);
+  else if (ln > 8) k = wave_bitonic<16>(k, lane);
+  else if (ln > 1) k = wave_bitonic<8>(k, lane);
+  if (lane < ln) {
+    const unsigned int hi = (unsigned int)(k >> 32), lo = (unsigned int)k;
+    idx_rows[(size_t)qi * PROV_CAP + lane] = (int)(by_index ? hi : lo);
+    d2_rows[(size_t)qi * PROV_CAP + lane] = __uint_as_float(by_index ? lo : hi);
+  }
+}
+
+// returns PCLMI_OK with *done = true when the call was served here
+static int radius_small_host(const pclmi_tree *t, HostSlot *h, const float *q, size_t nq, size_t q_stride_bytes,
+                             float r2, uint32_t max_nn, int sorted, uint64_t *offsets, int32_t **idx, float **d2,
+                             bool *done) {
+  *done = false;
+  static const bool off = [] { const char *e = getenv("PCLMI_RADIUS_SMALL"); return e && e[0] == '0'; }();
+  if (off || nq == 0 || nq > kSmallRadiusQueries || t->n == 0 || !(r2 > 0.f)) return PCLMI_OK;
+  if (max_nn == 0 || (size_t)max_nn > t->n) max_nn = 0;  // impl/kdtree_flann.hpp:125-135
+  const size_t q_bytes = nq * q_stride_bytes;
+  const size_t off_c = (q_bytes + 255) & ~(size_t)255;
+  const size_t off_i = off_c + ((nq * sizeof(unsigned int) + 255) & ~(size_t)255);
+  const size_t off_d = off_i + nq * PROV_CAP * sizeof(int32_t);
+  if (off_d + nq * PROV_CAP * sizeof(float) > HostSlot::kPinBytes) return PCLMI_OK;
+  RC(h->ensure(1, nq * (size_t)PROV_CAP * sizeof(u64) + 256));
+  u64 *prov = (u64 *)h->d[1];
+  unsigned int *d_scrap = (unsigned int *)(prov + nq * PROV_CAP);  // the traversal's overflow counter: not used here
+  std::memcpy(h->h_pin, q, q_bytes);
+  unsigned int *counts_h = (unsigned int *)(h->h_pin + off_c);
+  std::memset(counts_h, 0, nq * sizeof(unsigned int));  // a query with non-finite coordinates writes 0 anyway
+  const float tau_r = nextafterf(r2, 0.f);
+  // nearest-first keys unless the caller wants the plain unsorted list (ascending index, as the general path gives it)
+  const int by_index = (!sorted && !max_nn) ? 1 : 0;
+  launch_radius_traversal<2>(t, true, (const float *)h->d_pin, (int)(q_stride_bytes / 4), nullptr, (int)nq, r2, tau_r,
+                             by_index, (unsigned int *)(h->d_pin + off_c), (const u64 *)nullptr, prov, d_scrap, h->s);
+  hipLaunchKernelGGL(small_rows_sort_kernel, dim3((unsigned)nq), dim3(64), 0, h->s, (const u64 *)prov,
+                     (const unsigned int *)(h->d_pin + off_c), (int)nq, by_index, (int *)(h->d_pin + off_i),
+                     (float *)(h->d_pin + off_d));
+  PCLMI_HIP(hipGetLastError());
+  PCLMI_HIP(hipStreamSynchronize(h->s));
+  uint64_t total = 0;
+  for (size_t i = 0; i < nq; ++i) {
+    if (counts_h[i] > (unsigned int)PROV_CAP) return PCLMI_OK;  // the general path
+    offsets[i] = total;
+    total += max_nn ? std::min<uint64_t>(counts_h[i], max_nn) : counts_h[i];
+  }
+  offsets[nq] = total;
+  int32_t *hi = (int32_t *)malloc((total ? total : 1) * sizeof(int32_t));
+  float *hd = (float *)malloc((total ? total : 1) * sizeof(float));
+  if (!hi || !hd) {
+    free(hi);
+    free(hd);
+    set_error("out of host memory for %llu radius results", (unsigned long long)total);
+    return PCLMI_ERR_OOM;
+  }
+  const int32_t *ri = (const int32_t *)(h->h_pin + off_i);
+  const float *rd = (const float *)(h->h_pin + off_d);
+  for (size_t i = 0; i < nq; ++i) {
+    const size_t m = (size_t)(offsets[i + 1] - offsets[i]);
+    int32_t *oi = hi + offsets[i];
+    float *od = hd + offsets[i];
+    std::memcpy(oi, ri + i * PROV_CAP, m * sizeof(int32_t));
+    std::memcpy(od, rd + i * PROV_CAP, m * sizeof(float));
+    if (max_nn && !sorted && m > 1) {  // the nearest max_nn, listed by ascending index (as the general path does)
+      std::pair<int32_t, float> tmp[PROV_CAP];
+      for (size_t j = 0; j < m; ++j) tmp[j] = {oi[j], od[j]};
+      std::sort(tmp, tmp + m, [](const std::pair<int32_t, float> &a, const std::pair<int32_t, float> &b) {
+        return a.first < b.first;
+      });
+      for (size_t j = 0; j < m; ++j) {
+        oi[j] = tmp[j].first;
+        od[j] = tmp[j].second;
+      }
+    }
+  }
+  *idx = hi;
+  *d2 = hd;
+  *done = true;
+  return PCLMI_OK;
+}
+
 }  // namespace pclmi
 
 using namespace pclmi;
@@ -947,6 +1045,11 @@ int pclmi_radius(const pclmi_tree *t, const float *q, size_t nq, size_t q_stride
   HostSlotGuard hg(t);
   if (!hg.h) return PCLMI_ERR_HIP;
   HostSlot *h = hg.h;
+  {
+    bool done = false;
+    RC(radius_small_host(t, h, q, nq, q_stride_bytes, (float)(radius * radius), max_nn, sorted, offsets, idx, d2, &done));
+    if (done) return PCLMI_OK;
+  }
   int32_t *d_idx = nullptr;
   float *d_d2 = nullptr;
   uint64_t total = 0;

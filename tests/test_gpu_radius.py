@@ -134,3 +134,30 @@ def test_sparse_batches_take_the_per_lane_kernel(capi, orc):
     n = int(so[-1])
     assert np.array_equal(so, do[:30_002]) and np.array_equal(si, di[:n]) and np.array_equal(sd.view(np.int32), dd[:n].view(np.int32))
     _same(tb.radius(sparse[:3000], 2.5), orc.Tree(big).radius(sparse[:3000], 2.5, nthreads=8))
+
+
+def test_a_few_queries_from_the_host(capi, orc):
+    """pclmi_radius with up to 64 queries (pcl::KdTreeFLANN::radiusSearch, one point per call) takes two launches and
+    one wait - rows of at most 64 neighbours sorted by one wavefront each, written into pinned host memory.  Same CSR
+    output as the oracle in every mode; a query with more than 64 neighbours sends the call to the batch path."""
+    pts = util.uniform_cloud(50_000, 91)
+    q = util.uniform_cloud(64, 92)
+    q[5] = pts[123]                      # a query on a target point
+    q[9] = np.nan                        # and one that is not searchable
+    t = capi.Tree(pts)
+    r = 0.035                            # ~9 neighbours
+    for nq in (1, 2, 17, 64):
+        for max_nn, srt in ((0, True), (0, False), (4, True), (4, False), (1, True), (100000, True)):
+            _same(t.radius(q[:nq], r, max_nn, srt), orc.radius_brute(pts, q[:nq], r, max_nn, srt))
+    # rows of exactly 64 and of 65+ neighbours: the second kind falls through to the batch path
+    d = np.sort(((pts - q[0]) ** 2).sum(1, dtype=np.float32))
+    for m in (64, 65, 300):
+        rr = float(np.sqrt((np.float64(d[m - 1]) + np.float64(d[m])) / 2))
+        off, idx, d2 = t.radius(q[:3], rr)
+        assert off[1] - off[0] == m
+        _same((off, idx, d2), orc.radius_brute(pts, q[:3], rr))
+    # nothing in range, strided (16-byte) query rows
+    off, idx, d2 = t.radius(q[:4] + np.float32(50), 0.01)
+    assert off.tolist() == [0] * 5 and len(idx) == 0
+    q4 = np.concatenate([q[:8], np.ones((8, 1), np.float32)], axis=1)
+    _same(t.radius(q4, r), orc.radius_brute(pts, q[:8], r))
