@@ -329,6 +329,39 @@ def main():
                      "valu_issue_frac": pmc_valu_issue(pmc, kern_ms)},
     }
 
+    # ---- the same batches, TWO in flight: consecutive batches alternate between two streams (own result buffers), so
+    #      the start of a traversal fills the wavefront slots the previous one's last wavefronts leave empty (~half a
+    #      wavefront's life per slot: the tail of any single batch).  Reported beside the headline, which stays one
+    #      batch at a time so that its kernel durations read as the kernel alone.
+    try:
+        s2 = torch.cuda.Stream(device=dev)
+        idx2 = torch.empty_like(idx)
+        d22 = torch.empty_like(d2)
+        lanes = ((stream, idx, d2), (s2.cuda_stream, idx2, d22))
+
+        def step2(i):
+            st_, oi_, od_ = lanes[i & 1]
+            tree.knn_dev_async(q.data_ptr(), N_QUERY, 16, K, oi_.data_ptr(), od_.data_ptr(), st_)
+        for i in range(4):
+            step2(i)
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step2(i)
+        torch.cuda.synchronize()
+        barrier()
+        el2 = max_over_ranks(time.perf_counter() - t0)
+        same = bool(torch.equal(idx, idx2)) and bool(torch.equal(d2, d22))
+        out["two_batches_in_flight"] = {
+            "value": world * N_QUERY * args.steps / el2, "unit": "queries/s", "ms_per_batch": el2 / args.steps * 1e3,
+            "results_equal_headline": same,
+            "note": "pclmi_knn_dev_async, batches alternating between two streams with their own result buffers; "
+                    "ordering + traversal per batch as in the headline"}
+        del idx2, d22
+    except Exception as e:  # noqa: BLE001
+        out["two_batches_in_flight"] = {"error": repr(e)}
+
     partial["out"] = out
     # The side lines below never take the headline with them: a failure is recorded in the line, not raised.
     # ---- ICP iterations / s (configs[3]) -------------------------------------------------------
