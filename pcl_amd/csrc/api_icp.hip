@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <random>
 #include <unordered_map>
@@ -62,6 +63,7 @@ struct pclmi_icp_ctx {
   DevBuf<double> gpart;          // group sums of the step kernel's tail
   DevBuf<unsigned int> tickets;  // [groups] group tickets, then the launch ticket
   DevBuf<unsigned long long> loopbox;  // the resident loop's rows of tagged granules (allocated at its first launch)
+  size_t loop_hold = 0;  // workgroups this context has reserved on its device for resident launches (loop_reserve)
   unsigned groups = 1;
   pclmi_comm *comm = nullptr;    // exchange partner of pclmi_icp_run_dev (pclmi_icp_set_comm)
   double origin[3] = {0, 0, 0};
@@ -391,6 +393,30 @@ int pclmi_icp_begin_sharded(const pclmi_tree *target, const float *src, size_t n
   return PCLMI_OK;
 }
 
+// Resident launches of ONE process must fit on the chip TOGETHER: two of them that each hold part of the wavefront
+// slots and wait for workgroups that cannot start would stall each other until their bounded waits run out.  A
+// context reserves its workgroups before its first resident launch and gives them back when the host has waited for
+// its stream (pclmi_icp_state / pclmi_icp_end); a context that does not get them runs one launch per iteration.
+static std::atomic<long long> g_loop_blocks[64];
+static bool loop_reserve(pclmi_icp_ctx *c) {
+  if (c->loop_hold) return true;
+  const size_t cap = icp_loop_capacity(c->tree, c->plane), need = icp_step_blocks(c->n);
+  const int dev = c->tree->device & 63;
+  if (need > cap) return false;
+  const long long before = g_loop_blocks[dev].fetch_add((long long)need);
+  if ((size_t)before + need > cap) {
+    g_loop_blocks[dev].fetch_sub((long long)need);
+    return false;
+  }
+  c->loop_hold = need;
+  return true;
+}
+static void loop_release(pclmi_icp_ctx *c) {
+  if (!c->loop_hold) return;
+  g_loop_blocks[c->tree->device & 63].fetch_sub((long long)c->loop_hold);
+  c->loop_hold = 0;
+}
+
 // fused: the launch's last workgroup also exchanges the sums with the other ranks (when a communicator is attached)
 // and runs the solve; otherwise it only leaves the rank's sums in d_sums
 static int icp_step_enqueue(pclmi_icp_ctx *c, double max_correspondence_distance, double *d_sums, void *stream,
@@ -546,7 +572,7 @@ int pclmi_icp_run_dev(pclmi_icp_ctx *c, double max_correspondence_distance, int 
   // workgroups are all resident at once runs the iterations inside ONE launch (the resident loop): no launch boundary
   // between iterations.  Same arithmetic in the same order: the results are the per-iteration launches' bit for bit.
   c->dev_mode = true;
-  if (iterations > 1 && !c->scaled && icp_loop_fits(c->tree, c->n, c->plane))
+  if (iterations > 1 && !c->scaled && loop_reserve(c))
     return icp_step_enqueue(c, max_correspondence_distance, c->sums.p, stream, true, nullptr, nullptr, iterations);
   for (int i = 0; i < iterations; ++i) RC(icp_step_enqueue(c, max_correspondence_distance, c->sums.p, stream, true));
   return PCLMI_OK;
@@ -594,6 +620,7 @@ int pclmi_icp_state(pclmi_icp_ctx *c, float final_T[16], pclmi_icp_stats *stats)
   IcpDevState h;
   PCLMI_HIP(hipMemcpyAsync(&h, c->state.p, sizeof(h), hipMemcpyDeviceToHost, s));
   PCLMI_HIP(hipStreamSynchronize(s));
+  loop_release(c);  // every resident launch of this context has ended
   if (final_T) std::memcpy(final_T, h.final_T, sizeof(h.final_T));
   if (stats) {
     stats->iterations = h.iterations;
@@ -663,6 +690,10 @@ int pclmi_icp_end(pclmi_icp_ctx *c, float *aligned) {
     }
   } else {
     (void)hipStreamSynchronize(c->stream);
+  }
+  if (c->loop_hold) {
+    (void)hipStreamSynchronize(c->stream);
+    loop_release(c);
   }
   delete c;
   return rc;
@@ -1160,9 +1191,10 @@ int align_core(const pclmi_icp_params *p, const pclmi_tree *target, const float 
     set_identity(st.last_transform);
     int enqueued = 0;
     // an observer is called after every single iteration; the resident loop (pclmi_icp_run_dev) stops by itself
-    const bool resident = !obs.fn && !c->scaled && icp_loop_fits(c->tree, c->n, c->plane);
-    const int chunk_max = obs.fn ? 1 : resident ? (1 << 30) : world > 1 ? 16 : 8;
+    // (the reservation made here is the one pclmi_icp_run_dev finds; pclmi_icp_state gives it back)
     while (!rc) {
+      const bool resident = !obs.fn && !c->scaled && loop_reserve(c);
+      const int chunk_max = obs.fn ? 1 : resident ? (1 << 30) : world > 1 ? 16 : 8;
       const int chunk = std::max(1, std::min(chunk_max, p->max_iterations - enqueued));
       const int before = st.iterations;
       if ((rc = pclmi_icp_run_dev(c, p->max_correspondence_distance, chunk, nullptr))) break;

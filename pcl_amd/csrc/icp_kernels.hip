@@ -2282,11 +2282,12 @@ unsigned icp_step_blocks(size_t n) {
   return blocks ? blocks : 8u;  // an empty shard still launches: its sums are zeros, its tail runs the exchange
 }
 
-// Can every workgroup of a step launch over n points be resident at once (the resident loop's precondition)?
-bool icp_loop_fits(const pclmi_tree *t, size_t n, bool plane) {
-  if (!(plane || nn1_per_lane())) return false;
+// How many workgroups of the resident loop's step kernel fit on the chip at once (0: the loop is not available).
+// A launch of the loop needs ALL its workgroups resident: they wait for each other.
+size_t icp_loop_capacity(const pclmi_tree *t, bool plane) {
+  if (!(plane || nn1_per_lane())) return 0;
   static const bool off = [] { const char *e = getenv("PCLMI_ICP_LOOP"); return e && e[0] == '0'; }();
-  if (off) return false;
+  if (off) return 0;
   const int levels = lane_nearest_levels(t->M);
   const size_t lds_bytes = (size_t)ICP_WPB * levels * 64 * sizeof(float);
   int per_cu = 0, dev = 0;
@@ -2297,25 +2298,16 @@ bool icp_loop_fits(const pclmi_tree *t, size_t n, bool plane) {
   hipDeviceProp_t prop;
   if (e != hipSuccess || hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
     (void)hipGetLastError();
-    return false;
+    return 0;
   }
   // PCLMI_DEVICE_SHARE = n: n ranks of one job run on this GPU (rehearsals of the sharded loop on one device): their
   // resident loops wait for each other's sums, so all of them must fit on the chip together
   static const int share = [] { const char *e = getenv("PCLMI_DEVICE_SHARE"); const int v = e ? atoi(e) : 1; return v > 1 ? v : 1; }();
-  return (size_t)icp_step_blocks(n) * (size_t)share <= (size_t)per_cu * (size_t)prop.multiProcessorCount;
+  return (size_t)per_cu * (size_t)prop.multiProcessorCount / (size_t)share;
 }
+bool icp_loop_fits(const pclmi_tree *t, size_t n, bool plane) { return icp_step_blocks(n) <= icp_loop_capacity(t, plane); }
 size_t icp_loop_box_words(size_t n) { return ((size_t)icp_step_blocks(n) + icp_step_groups(n) + 1) * kLoopRow; }
 
-#ifdef PCLMI_WALK_COUNT
-}  // namespace pclmi
-// development aid: [0] max outer rounds of a wave's walk, [1] max descend steps, [2] sum of rounds, [3] waves
-extern "C" int pclmi_debug_walk_count(unsigned int out[4]) {
-  unsigned int z[4] = {0, 0, 0, 0};
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pclmi::dev::g_walk_count), sizeof(z)) != hipSuccess) return 1;
-  return hipMemcpyToSymbol(HIP_SYMBOL(pclmi::dev::g_walk_count), z, sizeof(z)) != hipSuccess;
-}
-namespace pclmi {
-#endif
 unsigned icp_step_groups(size_t n) { return (icp_step_blocks(n) + ICP_GROUP - 1) / ICP_GROUP; }
 
 void launch_icp_step(const pclmi_tree *t, float4 *d_pts, size_t n, bool apply, const Xf &T, double thr2,

@@ -324,6 +324,7 @@ void launch_icp_step(const pclmi_tree *t, float4 *d_pts, size_t n, bool apply, c
                      const float *scale = nullptr,
                      int loop_iters = 1 /* > 1: the resident loop, up to that many iterations in this ONE launch (needs
                                            st, tail.solve, icp_loop_fits(); not with d_keep_slot / d_raw_tgt) */);
+size_t icp_loop_capacity(const pclmi_tree *t, bool plane);  // workgroups the chip holds at once (0: no resident loop)
 bool icp_loop_fits(const pclmi_tree *t, size_t n, bool plane);
 size_t icp_loop_box_words(size_t n);  // 8-byte words of IcpTail::loopbox for a shard of n points
 // point-to-plane loop (d_tn_slot != nullptr above): PCLMI_ICP_NSUMS_PLANE sums per launch

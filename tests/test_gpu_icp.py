@@ -396,6 +396,35 @@ def test_resident_loop_equals_one_launch_per_iteration(capi, orc, plane):
     c.end(want_aligned=False)
 
 
+def test_resident_loops_of_one_process_share_the_chip(capi, orc):
+    """Resident launches wait for their own workgroups, so those of ONE process must fit on the chip together: a
+    context reserves its workgroups (430 each here, the chip holds 1024), the third context in flight does not get them
+    and runs one launch per iteration.  All finish, all give the solo result."""
+    tgt = surface_cloud(220_000, 181)
+    T0 = rigid(1.0, (1, 0, 1), (0.2, 0.1, -0.1))
+    src = orc.transform(tgt[::2] + np.float32(0.01), np.linalg.inv(T0))
+    tt = capi.Tree(tgt)
+    solo = capi.IcpShard(tt, src)
+    solo.run_dev(2.0, 8)
+    rc0, T_solo, st0 = solo.state()
+    out_solo = solo.end()
+    ctxs = [capi.IcpShard(tt, src) for _ in range(3)]
+    for c in ctxs:       # three launches in flight on three streams
+        c.run_dev(2.0, 8)
+    for c in ctxs:
+        rc, T, st = c.state()
+        assert rc == 0 and st.iterations == 8 and np.array_equal(T, T_solo)
+    for c in ctxs:       # and again: the reservations were given back by the state reads
+        c.run_dev(2.0, 2)
+    outs = []
+    for c in ctxs:
+        rc, T, st = c.state()
+        assert st.iterations == 10
+        outs.append(c.end())
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    assert st0.iterations == 8 and out_solo.shape == outs[0].shape
+
+
 def test_rccl_all_reduce_between_the_library_kernels():
     """tests/rccl_single_rank.py in a process of its own: a one-rank nccl (= RCCL) process group, the sharded
     device-resident driver and bench.py's N > 1 loop shape with the all-reduce issued between the library's step and
