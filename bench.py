@@ -580,6 +580,11 @@ def bench_extras(env, tree, target, q_host, q_dev, stream):
     r_ms, r_n = capi.timing_read(capi.TIMER_RADIUS, reset=True)
     capi.timing_enable(False)
     m_mean = tot.value / N_QUERY
+    pmc_rt, pmc_rt_from = pmc_summary("radius_union")
+    pmc_rs, _ = pmc_summary("prov_sort")
+    r_traffic = None
+    if pmc_traffic(pmc_rt) is not None and pmc_traffic(pmc_rs) is not None:
+        r_traffic = pmc_traffic(pmc_rt) + pmc_traffic(pmc_rs)  # traversal + provisional-row sort, per call
     r_algo = 16 * N_QUERY + 8 * (N_QUERY + 1) + 8 * tot.value + 16 * N_TARGET
     trav_ms = r_ms / reps
     ex["radius_1m"] = {"workload": "configs[2]: 1M-point target, 1M queries per GPU, r = %.3f (mean %.1f neighbours), "
@@ -589,7 +594,10 @@ def bench_extras(env, tree, target, q_host, q_dev, stream):
                                     "kernel_ms": trav_ms, "algorithmic_bytes_per_call": r_algo,
                                     "achieved": r_algo / (dt / reps) / 1e9, "achieved_note": "whole call",
                                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "frac": r_algo / (dt / reps) / 1e9 / HBM_PEAK_GBS, "traffic": None}}
+                                    "frac": r_algo / (dt / reps) / 1e9 / HBM_PEAK_GBS, "traffic": r_traffic,
+                                    "traffic_from": pmc_rt_from,
+                                    "traffic_note": "traversal + provisional-row sort (profiles/*radius_union*, "
+                                                    "*prov_sort*): the rows cross HBM twice"}}
     # ---- configs[4]: this GPU's share of the 100M-query k = 32 sweep on the 10M-point target
     log("extras: configs[4] sweep (10M-point tree build)")
     from pcl_amd import sweep
