@@ -912,12 +912,12 @@ int radius_search_dev(const pclmi_tree *t, Workspace *w, const float *d_q, size_
 
 // ---- a few queries from the host (pcl::KdTreeFLANN::radiusSearch, one point per call) --------------------------
 // The general path above is built for batches: ordering pass, count scan, totals read back, output arrays from the
-// cache, three downloads - a dozen enqueues and two host waits, 133 us for one query.  Up to kSmallRadiusQueries
+// cache, three downloads - a dozen enqueues and two host waits, 133 us for one query (204 for 1024).  Up to kSmallRadiusQueries
 // queries take two launches and ONE wait instead: the per-lane traversal leaves every query's first PROV_CAP keys in a
 // fixed-pitch row (device memory) and its count in the slot's pinned host buffer; one wavefront per query then sorts
 // the row and writes idx / d2 rows into the pinned buffer in place.  The host builds the CSR arrays from there.  A
 // query with more than PROV_CAP neighbours sends the call to the general path.
-constexpr size_t kSmallRadiusQueries = 64;
+constexpr size_t kSmallRadiusQueries = 1024;
 __global__ __launch_bounds__(64) void small_rows_sort_kernel(const u64 *__restrict__ prov,
                                                              const unsigned int *__restrict__ counts, int nq,
                                                              int by_index, int *__restrict__ idx_rows,

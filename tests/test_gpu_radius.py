@@ -137,17 +137,19 @@ def test_sparse_batches_take_the_per_lane_kernel(capi, orc):
 
 
 def test_a_few_queries_from_the_host(capi, orc):
-    """pclmi_radius with up to 64 queries (pcl::KdTreeFLANN::radiusSearch, one point per call) takes two launches and
+    """pclmi_radius with up to 1024 queries (pcl::KdTreeFLANN::radiusSearch, one point per call) takes two launches and
     one wait - rows of at most 64 neighbours sorted by one wavefront each, written into pinned host memory.  Same CSR
     output as the oracle in every mode; a query with more than 64 neighbours sends the call to the batch path."""
     pts = util.uniform_cloud(50_000, 91)
-    q = util.uniform_cloud(64, 92)
+    q = util.uniform_cloud(1024, 92)
     q[5] = pts[123]                      # a query on a target point
     q[9] = np.nan                        # and one that is not searchable
     t = capi.Tree(pts)
     r = 0.035                            # ~9 neighbours
-    for nq in (1, 2, 17, 64):
+    for nq in (1, 2, 17, 64, 65, 300, 1024, 1025):
         for max_nn, srt in ((0, True), (0, False), (4, True), (4, False), (1, True), (100000, True)):
+            if nq > 64 and (max_nn, srt) not in ((0, True), (4, False)):
+                continue
             _same(t.radius(q[:nq], r, max_nn, srt), orc.radius_brute(pts, q[:nq], r, max_nn, srt))
     # rows of exactly 64 and of 65+ neighbours: the second kind falls through to the batch path
     d = np.sort(((pts - q[0]) ** 2).sum(1, dtype=np.float32))
