@@ -643,6 +643,12 @@ int pclmi_icp_state(pclmi_icp_ctx *c, float final_T[16], pclmi_icp_stats *stats)
               h.last_pairs);
     return PCLMI_ERR_NOT_ENOUGH;
   }
+  if (h.status == PCLMI_ERR_HIP) {
+    set_error("a resident ICP launch gave up waiting for its own workgroups in iteration %d (other work held the GPU "
+              "for more than 5 s?): PCLMI_ICP_LOOP=0 runs one launch per iteration",
+              h.iterations + 1);
+    return PCLMI_ERR_HIP;
+  }
   return PCLMI_OK;
 }
 

@@ -646,7 +646,13 @@ __device__ __forceinline__ bool icp_loop_tail(const IcpTail &tail, double (*lds)
     if (lane == 13) s_pub[13] = seen ? 1u : 0u;
   }
   __syncthreads();
-  if (!s_pub[13]) return false;
+  if (!s_pub[13]) {  // the publication never came (workgroup 0 not on the chip?): say so, the host must not go on
+    if (tid == 0) {
+      st_state<true>(&tail.st->status, (int)PCLMI_ERR_HIP);
+      st_state<true>(&tail.st->done, 1);
+    }
+    return false;
+  }
 #pragma unroll
   for (int j = 0; j < 12; ++j) T.m[j] = __uint_as_float(s_pub[j]);
   const bool go_on = s_pub[12] == 0u;

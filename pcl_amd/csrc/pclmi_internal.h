@@ -266,7 +266,8 @@ struct IcpDevState {
   int max_iterations, min_correspondences;
   double fit, tdelta;
   double transformation_epsilon, euclidean_fitness_epsilon;
-  unsigned int ticket;  // unused (the arrival tickets of the step kernel's tail live in IcpTail)
+  unsigned int ticket;  // the resident loop's iteration counter since the context began: the tag of its hand-offs
+                        // (the arrival tickets of the per-iteration launches live in IcpTail)
   // wall_clock64() (100 MHz) of the last step launch: [0] workgroup 0 started, [1] last workgroup arrived,
   // [2] sums ready (after the exchange), [3] solve done.  Development aid (pclmi_debug_icp_ticks).
   unsigned long long ticks[4];
