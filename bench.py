@@ -334,6 +334,8 @@ def main():
     #      wavefront's life per slot: the tail of any single batch).  Reported beside the headline, which stays one
     #      batch at a time so that its kernel durations read as the kernel alone.
     try:
+        if args.no_extras:
+            raise RuntimeError("skipped (--no-extras)")
         s2 = torch.cuda.Stream(device=dev)
         idx2 = torch.empty_like(idx)
         d22 = torch.empty_like(d2)
