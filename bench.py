@@ -783,6 +783,22 @@ def bench_extras(env, tree, target, q_host, q_dev, stream):
             nrm[name] = {"value": 5 * len(tgt) / (time.perf_counter() - t0), "unit": "normals/s"}
         ex["normals_1m"] = {"workload": "NormalEstimation over every point of the 1M-point surface cloud, cloud and "
                                         "normals in HBM, one fused search + plane-fit kernel per call", **nrm}
+        # ---- configs[1]'s surface-like variant (real clouds are 2-manifolds): k = 16, the 1M-point surface
+        #      cloud as target, its own points moved by sigma = 0.5 noise as queries
+        d_qs = torch.from_numpy((tgt + np.random.default_rng(SEED_Q + 20).normal(0, 0.5, tgt.shape)).astype(np.float32)).to(dev)
+        s_idx = torch.empty((len(tgt), K), dtype=torch.int32, device=dev)
+        s_d2 = torch.empty((len(tgt), K), dtype=torch.float32, device=dev)
+        for _ in range(3):
+            t2.knn_dev_pipelined(d_qs.data_ptr(), len(tgt), 12, K, s_idx.data_ptr(), s_d2.data_ptr(), stream)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            t2.knn_dev_pipelined(d_qs.data_ptr(), len(tgt), 12, K, s_idx.data_ptr(), s_d2.data_ptr(), stream)
+        torch.cuda.synchronize()
+        ex["knn16_surface_1m"] = {"workload": "configs[1] on the surface-like cloud (64 noisy planes): 1M-point target, "
+                                              "1M queries (target points + sigma 0.5 noise), k = 16",
+                                  "value": 10 * len(tgt) / (time.perf_counter() - t0), "unit": "queries/s"}
+        del d_qs, s_idx, s_d2
         # ---- tree build (pcl::KdTreeFLANN::setInputCloud): device builder
         tb = {}
         for name, cloud_h in (("1m", tgt), ("10m", big)):
@@ -835,10 +851,30 @@ def cpu_baseline(target, q_host, idx, d2):
     t1 = time.perf_counter()
     tree.knn(q_host[:200_000], K, nthreads=1)
     dt1 = time.perf_counter() - t1
-    return {"value": reps * nq / dt, "unit": "queries/s", "cores": cores, "kind": "port", "flags": flags,
-            "sample": "all %d queries x %d passes, FLANN-style kd-tree (leaf 15), OpenMP over queries" % (nq, reps),
-            "single_thread_value": 200_000 / dt1, "single_query_us": dt1 / 200_000 * 1e6,
-            "gpu_matches_cpu_bitexact_on_20000": parity}
+    res = {"value": reps * nq / dt, "unit": "queries/s", "cores": cores, "kind": "port", "flags": flags,
+           "sample": "all %d queries x %d passes, FLANN-style kd-tree (leaf 15), OpenMP over queries" % (nq, reps),
+           "single_thread_value": 200_000 / dt1, "single_query_us": dt1 / 200_000 * 1e6,
+           "gpu_matches_cpu_bitexact_on_20000": parity}
+    # ICP iterations/s of the same port on configs[3]'s clouds (SURVEY 8d asks for both): the oracle's loop with the
+    # searches spread over the cores; (4-iteration align - 1-iteration align) / 3, so the tree build cancels
+    try:
+        tgt_i, src_i, _ = icp_clouds()
+        pi = orc.icp_default_params()
+        pi.ransac_iterations, pi.max_correspondence_distance = 0, 25.0
+        pi.transformation_epsilon, pi.euclidean_fitness_epsilon = 0.0, -1.0
+
+        def icp_run(n_it):
+            pi.max_iterations = n_it
+            t = time.perf_counter()
+            rc_, _, _, st_ = orc.icp_align(src_i, tgt_i, pi, nthreads=cores)
+            assert rc_ == 0 and st_.iterations == n_it
+            return time.perf_counter() - t
+        ta, tb = icp_run(1), icp_run(4)
+        res["icp_iterations_per_s"] = 3.0 / max(tb - ta, 1e-9)
+        res["icp_sample"] = "configs[3] clouds (1M x 1M, RANSAC off), iterations 2-4 of the oracle's loop, %d threads" % cores
+    except Exception as e:  # noqa: BLE001
+        res["icp_error"] = repr(e)
+    return res
 
 
 if __name__ == "__main__":
