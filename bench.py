@@ -600,6 +600,39 @@ def bench_extras(env, tree, target, q_host, q_dev, stream):
                                     "traffic_from": pmc_rt_from,
                                     "traffic_note": "traversal + provisional-row sort (profiles/*radius_union*, "
                                                     "*prov_sort*): the rows cross HBM twice"}}
+    # the enqueue-only form (caller-owned result arrays, nothing waits for the host): one stream, then two calls in flight
+    try:
+        cap = int(tot.value * 1.1) + 4096
+        lanes = []
+        for ss in (torch.cuda.current_stream(dev), torch.cuda.Stream(device=dev)):
+            lanes.append((ss, torch.empty(N_QUERY + 1, dtype=torch.int64, device=dev),
+                          torch.empty(cap, dtype=torch.int32, device=dev), torch.empty(cap, dtype=torch.float32, device=dev),
+                          torch.zeros(2, dtype=torch.int64, device=dev)))
+
+        def radius_async(i, n_lanes):
+            ss, o_, i_, d_, st_ = lanes[i % n_lanes]
+            rc = lib.pclmi_radius_dev_async(tree.h, q_dev.data_ptr(), N_QUERY, 16, r, 1, o_.data_ptr(), i_.data_ptr(),
+                                            d_.data_ptr(), cap, st_.data_ptr(), ss.cuda_stream)
+            assert rc == 0, lib.pclmi_last_error()
+        asy = {}
+        for name, n_lanes in (("one_stream", 1), ("two_calls_in_flight", 2)):
+            for i in range(4):
+                radius_async(i, n_lanes)
+            torch.cuda.synchronize()
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(20):
+                radius_async(i, n_lanes)
+            torch.cuda.synchronize()
+            barrier()
+            dta = max_over_ranks(time.perf_counter() - t0)
+            asy[name] = {"value": world * N_QUERY * 20 / dta, "unit": "queries/s", "ms_per_call": dta / 20 * 1e3}
+        assert lanes[0][4].tolist() == [tot.value, 0] and lanes[1][4].tolist() == [tot.value, 0]
+        ex["radius_1m"]["enqueue_only"] = dict(asy, note="pclmi_radius_dev_async: result arrays of a given capacity "
+                                                    "brought by the caller, status read afterwards")
+        del lanes
+    except Exception as e:  # noqa: BLE001
+        ex["radius_1m"]["enqueue_only"] = {"error": repr(e)}
     # ---- configs[4]: this GPU's share of the 100M-query k = 32 sweep on the 10M-point target
     log("extras: configs[4] sweep (10M-point tree build)")
     from pcl_amd import sweep

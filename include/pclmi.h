@@ -168,6 +168,15 @@ int pclmi_radius(const pclmi_tree *t, const float *queries, size_t nq, size_t q_
 int pclmi_radius_dev(const pclmi_tree *t, const float *d_queries, size_t nq, size_t q_stride_bytes,
                      double radius, uint32_t max_nn, int sorted, uint64_t *d_offsets,
                      int32_t **d_idx, float **d_d2, uint64_t *total, void *stream);
+/* Enqueue-only variant for device-resident pipelines (the same batched radiusSearch, search.h:412-434): the CALLER
+ * brings the result arrays - d_idx / d_d2 with room for `capacity` neighbours in all - so nothing waits for the host
+ * and consecutive calls queue up (or overlap on two streams).  All neighbours are returned (max_nn = 0).
+ * d_status (device, 2 words) receives {offsets[nq], flag}: flag != 0 means the arrays were NOT written - a query
+ * has more than 64 neighbours or the total exceeds the capacity - and the search must be repeated with
+ * pclmi_radius_dev (d_offsets is valid either way).  Read it once `stream` has reached this point. */
+int pclmi_radius_dev_async(const pclmi_tree *t, const float *d_queries, size_t nq, size_t q_stride_bytes,
+                           double radius, int sorted, uint64_t *d_offsets, int32_t *d_idx, float *d_d2,
+                           uint64_t capacity, uint64_t *d_status, void *stream);
 void pclmi_free(void *host_ptr);
 void pclmi_free_dev(void *device_ptr);
 

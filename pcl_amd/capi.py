@@ -79,6 +79,8 @@ SIGNATURES = {
     "pclmi_knn_dev_noalloc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p,
                                         C.c_void_p, C.c_void_p]),
     "pclmi_knn_kernel_name": (C.c_char_p, [C.c_void_p, C.c_size_t, C.c_int]),
+    "pclmi_radius_dev_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_double, C.c_int, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "pclmi_radius": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_double, C.c_uint32, C.c_int,
                                C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "pclmi_radius_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_double, C.c_uint32, C.c_int,
@@ -337,6 +339,13 @@ class Tree:
     def knn_dev_noalloc(self, q_ptr, nq, q_stride_bytes, k, idx_ptr, d2_ptr, stream=None):
         """pclmi_knn_dev_noalloc: enqueue-only, scratch in the library's static device array (no hipMalloc)."""
         _check(load_library().pclmi_knn_dev_noalloc(self.h, q_ptr, nq, q_stride_bytes, k, idx_ptr, d2_ptr, stream))
+
+    def radius_dev_async(self, q_ptr, nq, q_stride_bytes, radius, offsets_ptr, idx_ptr, d2_ptr, capacity, status_ptr,
+                         sorted_results=True, stream=None):
+        """pclmi_radius_dev_async: enqueue-only, caller-owned result arrays of `capacity` entries."""
+        _check(load_library().pclmi_radius_dev_async(self.h, q_ptr, nq, q_stride_bytes, float(radius),
+                                                     int(sorted_results), offsets_ptr, idx_ptr, d2_ptr, capacity,
+                                                     status_ptr, stream))
 
     def radius(self, queries, radius, max_nn=0, sorted_results=True):
         """Returns CSR (offsets[nq+1], idx, d2) as numpy arrays."""

@@ -910,6 +910,61 @@ int radius_search_dev(const pclmi_tree *t, Workspace *w, const float *d_q, size_
   return PCLMI_OK;
 }
 
+// ---- enqueue-only form (pclmi_radius_dev_async) ---------------------------------------------------------------
+// What the synchronous call waits for is the output SIZE.  A caller that brings result arrays of its own - a capacity -
+// does not need to know it before the kernels run: traversal into provisional rows, scan of the counts into the
+// caller's offsets, sort of the rows into the caller's arrays (which does nothing when a query overflowed its row or
+// the total exceeds the capacity), and a status pair the caller reads whenever it likes.  Nothing waits for the
+// host, so consecutive calls queue up behind each other - or overlap on two streams, the end of one traversal under
+// the start of the next.
+__global__ void radius_status_kernel(const u64 *__restrict__ offsets, int nq, const unsigned int *__restrict__ n_over,
+                                     u64 cap, u64 *__restrict__ status) {
+  status[0] = offsets[nq];
+  status[1] = (*n_over != 0u || offsets[nq] > cap) ? 1ull : 0ull;
+}
+
+int radius_search_enqueue(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, size_t qsf, float r2,
+                          int sorted, uint64_t *d_offsets, int32_t *d_idx, float *d_d2, uint64_t cap,
+                          uint64_t *d_status, hipStream_t s) {
+  PCLMI_CHECK(nq < ((size_t)1 << 31) - 1, PCLMI_ERR_UNSUPPORTED, "more than 2^31-2 queries in one call");
+  PCLMI_CHECK(nq * (size_t)PROV_CAP * sizeof(u64) <= ((size_t)2 << 30), PCLMI_ERR_UNSUPPORTED,
+              "more than %zu queries in one enqueue-only radius search", ((size_t)2 << 30) / (PROV_CAP * sizeof(u64)));
+  if (nq == 0 || t->n == 0 || !(r2 > 0.f)) {
+    PCLMI_HIP(hipMemsetAsync(d_offsets, 0, (nq + 1) * sizeof(uint64_t), s));
+    PCLMI_HIP(hipMemsetAsync(d_status, 0, 2 * sizeof(uint64_t), s));
+    return PCLMI_OK;
+  }
+  const int32_t *order = nullptr;
+  RC(launch_morton_order(t, w, d_q, nq, qsf, nullptr, nullptr, s, &order));
+  const size_t counts_bytes = ((nq + 4) * sizeof(unsigned int) + 15) & ~(size_t)15;
+  RC(w->ensure_buf(0, counts_bytes));
+  RC(w->ensure_buf(1, nq * (size_t)PROV_CAP * sizeof(u64)));
+  unsigned int *d_counts = (unsigned int *)w->buf[0];
+  unsigned int *d_nover = d_counts + nq + 3;
+  u64 *prov = (u64 *)w->buf[1];
+  PCLMI_HIP(hipMemsetAsync(d_counts, 0, counts_bytes, s));
+  const float tau_r = nextafterf(r2, 0.f);
+  const int by_index = sorted ? 0 : 1;
+  static const int forced = [] {
+    const char *e = getenv("PCLMI_KNN");
+    return !e ? 0 : (e[0] == 'u' ? 1 : (e[0] == 'l' ? 2 : 0));
+  }();
+  const bool per_lane = forced ? forced == 2 : nq * 4 < t->n;
+  {
+    TimingScope ts(PCLMI_TIMER_RADIUS, s);
+    launch_radius_traversal<2>(t, per_lane, d_q, (int)qsf, order, (int)nq, r2, tau_r, by_index, d_counts,
+                               (const u64 *)nullptr, prov, d_nover, s);
+  }
+  RC(scan_counts(w, d_counts, nq, (u64 *)d_offsets, s));
+  hipLaunchKernelGGL(prov_sort_kernel, dim3((unsigned)((nq + SORT64_WPB * SORT64_SEGS - 1) / (SORT64_WPB * SORT64_SEGS))),
+                     dim3(64 * SORT64_WPB), 0, s, (const u64 *)prov, (const unsigned int *)d_counts,
+                     (const u64 *)d_offsets, (int)nq, by_index, d_idx, d_d2, (const unsigned int *)d_nover, (u64)cap);
+  hipLaunchKernelGGL(radius_status_kernel, dim3(1), dim3(1), 0, s, (const u64 *)d_offsets, (int)nq,
+                     (const unsigned int *)d_nover, (u64)cap, (u64 *)d_status);
+  PCLMI_HIP(hipGetLastError());
+  return PCLMI_OK;
+}
+
 // ---- a few queries from the host (pcl::KdTreeFLANN::radiusSearch, one point per call) --------------------------
 // The general path above is built for batches: ordering pass, count scan, totals read back, output arrays from the
 // cache, three downloads - a dozen enqueues and two host waits, 133 us for one query (204 for 1024).  Up to kSmallRadiusQueries
@@ -1028,6 +1083,24 @@ int pclmi_radius_dev(const pclmi_tree *t, const float *d_q, size_t nq, size_t q_
   WsGuard g(t, s);
   return radius_search_dev(t, g.w, d_q, nq, q_stride_bytes / 4, r2, max_nn, sorted, d_offsets, d_idx, d_d2, total,
                            s);
+}
+
+int pclmi_radius_dev_async(const pclmi_tree *t, const float *d_q, size_t nq, size_t q_stride_bytes, double radius,
+                           int sorted, uint64_t *d_offsets, int32_t *d_idx, float *d_d2, uint64_t capacity,
+                           uint64_t *d_status, void *stream) {
+  PCLMI_CHECK(t && d_offsets && d_status, PCLMI_ERR_INVALID, "NULL argument");
+  PCLMI_CHECK(nq == 0 || d_q, PCLMI_ERR_INVALID, "queries are NULL");
+  PCLMI_CHECK(capacity == 0 || (d_idx && d_d2), PCLMI_ERR_INVALID, "NULL result arrays");
+  PCLMI_CHECK(q_stride_bytes >= 12 && q_stride_bytes % 4 == 0, PCLMI_ERR_INVALID, "bad query stride %zu",
+              q_stride_bytes);
+  PCLMI_CHECK(pclmi_device_count() > 0, PCLMI_ERR_NO_DEVICE, "no HIP device visible: libpclmi has no CPU fallback");
+  PCLMI_HIP(hipSetDevice(t->device));
+  hipStream_t s = stream ? (hipStream_t)stream : t->stream;
+  Workspace *w = acquire_ws(t, s);
+  const int rc = radius_search_enqueue(t, w, d_q, nq, q_stride_bytes / 4, (float)(radius * radius), sorted, d_offsets,
+                                       d_idx, d_d2, capacity, d_status, s);
+  release_ws_async(t, w, s);  // the next user of w is ordered behind this call's kernels by an event
+  return rc;
 }
 
 int pclmi_radius(const pclmi_tree *t, const float *q, size_t nq, size_t q_stride_bytes, double radius,

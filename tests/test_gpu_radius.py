@@ -163,3 +163,62 @@ def test_a_few_queries_from_the_host(capi, orc):
     assert off.tolist() == [0] * 5 and len(idx) == 0
     q4 = np.concatenate([q[:8], np.ones((8, 1), np.float32)], axis=1)
     _same(t.radius(q4, r), orc.radius_brute(pts, q[:8], r))
+
+
+def test_enqueue_only_radius_search(capi, orc):
+    """pclmi_radius_dev_async: caller-owned result arrays of a given capacity, nothing waits for the host.  Same CSR
+    output as the synchronous call; the status pair flags a row of more than 64 neighbours or a capacity that is too
+    small (the offsets are valid either way); two calls in flight on two streams do not disturb each other."""
+    import torch
+    pts = util.uniform_cloud(200_000, 93)
+    q = util.uniform_cloud(100_000, 94)
+    q[7] = np.nan
+    t = capi.Tree(pts)
+    r = 0.022                                     # ~9 neighbours, at most a few dozen
+    dq = torch.from_numpy(q).cuda()
+    nq = len(q)
+
+    def bufs(cap):
+        return (torch.empty(nq + 1, dtype=torch.int64, device="cuda"), torch.empty(cap, dtype=torch.int32, device="cuda"),
+                torch.empty(cap, dtype=torch.float32, device="cuda"), torch.zeros(2, dtype=torch.int64, device="cuda"))
+    for srt in (True, False):
+        ref = t.radius(q, r, 0, srt)
+        total = int(ref[0][-1])
+        off, idx, d2, st = bufs(total + 1000)
+        t.radius_dev_async(dq.data_ptr(), nq, 12, r, off.data_ptr(), idx.data_ptr(), d2.data_ptr(), total + 1000,
+                           st.data_ptr(), sorted_results=srt)
+        torch.cuda.synchronize()
+        assert st.tolist() == [total, 0]
+        _same((off.cpu().numpy(), idx[:total].cpu().numpy(), d2[:total].cpu().numpy()), ref)
+    # capacity one short: flagged, offsets still right
+    off2, idx2, d22, st2 = bufs(total - 1)
+    t.radius_dev_async(dq.data_ptr(), nq, 12, r, off2.data_ptr(), idx2.data_ptr(), d22.data_ptr(), total - 1, st2.data_ptr())
+    torch.cuda.synchronize()
+    assert st2.tolist() == [total, 1] and np.array_equal(off2.cpu().numpy(), ref[0])
+    # a radius with more than 64 neighbours for some query: flagged
+    big = t.radius(q[:1000], 0.08)
+    assert np.diff(big[0]).max() > 64
+    off3, idx3, d23, st3 = bufs(int(big[0][-1]) + 10)
+    t.radius_dev_async(dq.data_ptr(), 1000, 12, 0.08, off3.data_ptr(), idx3.data_ptr(), d23.data_ptr(),
+                       int(big[0][-1]) + 10, st3.data_ptr())
+    torch.cuda.synchronize()
+    assert st3.tolist() == [int(big[0][-1]), 1] and np.array_equal(off3[:1001].cpu().numpy(), big[0])
+    # two calls in flight on two streams, different radii
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    refs = [t.radius(q, rr) for rr in (0.02, 0.025)]
+    outs = [bufs(int(rf[0][-1])) for rf in refs]
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for (rr, o, rf, ss) in zip((0.02, 0.025), outs, refs, (s1, s2)):
+            t.radius_dev_async(dq.data_ptr(), nq, 12, rr, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(),
+                               int(rf[0][-1]), o[3].data_ptr(), stream=ss.cuda_stream)
+    torch.cuda.synchronize()
+    for o, rf in zip(outs, refs):
+        assert o[3].tolist() == [int(rf[0][-1]), 0]
+        _same((o[0].cpu().numpy(), o[1].cpu().numpy(), o[2].cpu().numpy()), rf)
+    # nothing to find / nothing to search
+    off4, idx4, d24, st4 = bufs(16)
+    t.radius_dev_async(dq.data_ptr(), 50, 12, 1e-9, off4.data_ptr(), idx4.data_ptr(), d24.data_ptr(), 16, st4.data_ptr())
+    t.radius_dev_async(dq.data_ptr(), 0, 12, 0.1, off4.data_ptr(), idx4.data_ptr(), d24.data_ptr(), 16, st4.data_ptr())
+    torch.cuda.synchronize()
+    assert st4.tolist() == [0, 0] and off4[0].item() == 0
