@@ -391,7 +391,13 @@ int pclmi_icp_end(pclmi_icp_ctx *ctx, float *aligned);
  *         pclmi_icp_solve_dev(ctx, d_sums, stream)
  *   pclmi_icp_state(ctx, final_T, stats)                  synchronises and reads the state back
  *   pclmi_icp_end(ctx, aligned)
- * pclmi_icp_run_dev enqueues `iterations` x (step, solve) for the single-GPU case.  The device
+ * pclmi_icp_run_dev enqueues `iterations` iterations, each ONE kernel (step, reduction, exchange with the peers
+ * when a communicator is attached, solve).  A shard whose workgroups all fit on the chip at once (up to ~262k
+ * points) runs them inside ONE launch - the workgroups wait for the next transform instead of ending; same
+ * arithmetic in the same order, bit-identical state.  Such launches of one process reserve their workgroups on the
+ * device (a context that does not get them runs one launch per iteration); if other work keeps a launch's
+ * workgroups off the chip for more than 5 s, pclmi_icp_state returns PCLMI_ERR_HIP (PCLMI_ICP_LOOP=0 disables
+ * the resident form).  The device
  * solve is the code of pclmi_icp_solve compiled for the GPU (IEEE fp64, no contraction): same
  * sums, same bits.  A context is driven EITHER this way or with pclmi_icp_set_transform.
  * pclmi_icp_state returns PCLMI_ERR_NOT_ENOUGH when an iteration found fewer pairs than
