@@ -2309,7 +2309,8 @@ size_t icp_loop_capacity(const pclmi_tree *t, bool plane) {
   // PCLMI_DEVICE_SHARE = n: n ranks of one job run on this GPU (rehearsals of the sharded loop on one device): their
   // resident loops wait for each other's sums, so all of them must fit on the chip together
   static const int share = [] { const char *e = getenv("PCLMI_DEVICE_SHARE"); const int v = e ? atoi(e) : 1; return v > 1 ? v : 1; }();
-  return (size_t)per_cu * (size_t)prop.multiProcessorCount / (size_t)share;
+  // (workgroup 0 adds up the group sums in one batch of <= 8 entries per lane: at most 64 groups of ICP_GROUP)
+  return std::min((size_t)per_cu * (size_t)prop.multiProcessorCount / (size_t)share, (size_t)64 * ICP_GROUP);
 }
 bool icp_loop_fits(const pclmi_tree *t, size_t n, bool plane) { return icp_step_blocks(n) <= icp_loop_capacity(t, plane); }
 size_t icp_loop_box_words(size_t n) { return ((size_t)icp_step_blocks(n) + icp_step_groups(n) + 1) * kLoopRow; }
