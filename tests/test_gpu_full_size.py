@@ -279,3 +279,27 @@ def test_fp32_reference_estimator_is_within_its_accumulation_bound(capi, orc, n)
     assert np.abs(T[:3, 3] - T32[:3, 3]).max() <= bound_t, (np.abs(T[:3, 3] - T32[:3, 3]).max(), bound_t)
     assert np.abs(T[:3, :3] - T32[:3, :3]).max() <= bound_r, (np.abs(T[:3, :3] - T32[:3, :3]).max(), bound_r)
     tree.close()
+
+
+def test_c4_shards_of_8_and_4_gpus_resident_loop(capi, orc):
+    # configs[3] as rank 4 of 8 (125k source points) and rank 1 of 4 (250k) see it: the shard's iterations run inside
+    # ONE launch (every workgroup resident); the state after 12 iterations equals 12 launches of one iteration, bit for
+    # bit, and the shards' sums are those of the full cloud's loop restricted to the shard (same pairs per point)
+    tgt, src, T0 = c4_clouds()
+    tree = capi.Tree(tgt)
+    for rank, world in ((4, 8), (1, 4)):
+        a = capi.IcpShard(tree, src, rank=rank, world=world)
+        b = capi.IcpShard(tree, src, rank=rank, world=world)
+        assert a.shard_size == len(src) // world
+        a.run_dev(25.0, 12)
+        for _ in range(12):
+            b.run_dev(25.0, 1)
+        rca, Ta, sta = a.state()
+        rcb, Tb, stb = b.state()
+        assert rca == rcb == 0 and sta.iterations == stb.iterations == 12
+        assert sta.last_correspondences == stb.last_correspondences == a.shard_size
+        assert np.array_equal(Ta, Tb) and sta.fitness_delta == stb.fitness_delta
+        assert np.abs(Ta - T0).max() < 5e-2  # one shard alone already finds the motion of the whole cloud
+        a.end(want_aligned=False)
+        b.end(want_aligned=False)
+    tree.close()
