@@ -498,8 +498,12 @@ __device__ __forceinline__ void lane_traverse(const TreeView &t, float qx, float
         if (2 * node + 1 < M) {
           // two levels per step (half as many dependent loads): the four grandchildren boxes; a child's
           // bound is the smaller of its two children's box distances
-          const float4 *b = reinterpret_cast<const float4 *>(t.box + (size_t)node * 32);
-          const float4 a0 = b[0], a1 = b[1], a2 = b[2], a3 = b[3], c0 = b[4], c1 = b[5], c2 = b[6], c3 = b[7];
+          // (a box is lo.xyz hi.xyz + two pad floats: 24 of its 32 bytes are fetched)
+          const float *bf = t.box + (size_t)node * 32;
+          const float4 a0 = *reinterpret_cast<const float4 *>(bf), a2 = *reinterpret_cast<const float4 *>(bf + 8);
+          const float4 c0 = *reinterpret_cast<const float4 *>(bf + 16), c2 = *reinterpret_cast<const float4 *>(bf + 24);
+          const float2 a1 = *reinterpret_cast<const float2 *>(bf + 4), a3 = *reinterpret_cast<const float2 *>(bf + 12);
+          const float2 c1 = *reinterpret_cast<const float2 *>(bf + 20), c3 = *reinterpret_cast<const float2 *>(bf + 28);
           const f2v m01 = box_dist_pk(q2x, q2y, q2z, f2v{a0.x, a2.x}, f2v{a0.y, a2.y}, f2v{a0.z, a2.z},
                                       f2v{a0.w, a2.w}, f2v{a1.x, a3.x}, f2v{a1.y, a3.y});
           const f2v m23 = box_dist_pk(q2x, q2y, q2z, f2v{c0.x, c2.x}, f2v{c0.y, c2.y}, f2v{c0.z, c2.z},
