@@ -1596,6 +1596,8 @@ __device__ __forceinline__ void map_put(ShufMap &m, int j, int v, int lane) {
 // position in the pair list -> source row: the pos-th set bit of the pair mask
 // lpre: the exclusive prefix in LDS (up to kSbLds blocks of 1024 rows), else nullptr: read from a.sb_prefix
 constexpr int kSbLds = 4096;
+// AG: the mask words were written by other workgroups of THIS launch (ransac_words_draw_kernel): agent-scope loads
+template <bool AG = false>
 __device__ __forceinline__ int select_row(const RansacLoopArgs &a, const unsigned int *lpre, int pos) {
   int lo = 0, hi = a.nsb - 1;  // last block whose prefix is <= pos
   auto pre = [&](int i) {
@@ -1608,13 +1610,18 @@ __device__ __forceinline__ int select_row(const RansacLoopArgs &a, const unsigne
     else hi = mid - 1;
   }
   int rem = pos - pre(lo);
-  const ulonglong2 *w2 = reinterpret_cast<const ulonglong2 *>(a.keep_bits + (size_t)lo * (kSbRows / 64));
   unsigned long long wv[kSbRows / 64];
+  if (AG) {
 #pragma unroll
-  for (int i = 0; i < kSbRows / 128; ++i) {  // the block's 16 words, all loads in flight
-    const ulonglong2 t = w2[i];
-    wv[2 * i] = t.x;
-    wv[2 * i + 1] = t.y;
+    for (int i = 0; i < kSbRows / 64; ++i) wv[i] = ld_state<true>(a.keep_bits + (size_t)lo * (kSbRows / 64) + i);
+  } else {
+    const ulonglong2 *w2 = reinterpret_cast<const ulonglong2 *>(a.keep_bits + (size_t)lo * (kSbRows / 64));
+#pragma unroll
+    for (int i = 0; i < kSbRows / 128; ++i) {  // the block's 16 words, all loads in flight
+      const ulonglong2 t = w2[i];
+      wv[2 * i] = t.x;
+      wv[2 * i + 1] = t.y;
+    }
   }
   int wi = kSbRows / 64;
   unsigned long long bits = 0;
@@ -1634,7 +1641,8 @@ __device__ __forceinline__ int select_row(const RansacLoopArgs &a, const unsigne
   return lo * kSbRows + wi * 64 + (__ffsll((long long)bits) - 1);
 }
 
-__global__ __launch_bounds__(64) void ransac_draw_loop_kernel(RansacLoopArgs a, int first, int draws) {
+template <bool AG>
+__device__ __forceinline__ void ransac_draw_body(const RansacLoopArgs &a, int first, int draws) {
   __shared__ unsigned int mt[624];
   __shared__ int jpos[kRansacBatch][3], gval[kRansacBatch][3], dpos[kRansacBatch][3];
   __shared__ float4 six[kRansacBatch][6];
@@ -1720,11 +1728,11 @@ __global__ __launch_bounds__(64) void ransac_draw_loop_kernel(RansacLoopArgs a, 
     const int chunk = (a.nsb + 63) / 64;
     const int b0 = lane * chunk, b1 = min(a.nsb, b0 + chunk);
     if (pre_lds) {
-      for (int i = lane; i < a.nsb; i += 64) lpre[i] = a.sb_cnt[i];  // independent loads, all in flight
+      for (int i = lane; i < a.nsb; i += 64) lpre[i] = ld_state<AG>(&a.sb_cnt[i]);  // independent loads, all in flight
       __syncthreads();
     }
     unsigned int sum = 0;
-    for (int i = b0; i < b1; ++i) sum += pre_lds ? lpre[i] : a.sb_cnt[i];
+    for (int i = b0; i < b1; ++i) sum += pre_lds ? lpre[i] : ld_state<AG>(&a.sb_cnt[i]);
     unsigned int incl = sum;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -1733,7 +1741,7 @@ __global__ __launch_bounds__(64) void ransac_draw_loop_kernel(RansacLoopArgs a, 
     }
     unsigned int run = incl - sum;
     for (int i = b0; i < b1; ++i) {
-      const unsigned int c = pre_lds ? lpre[i] : a.sb_cnt[i];
+      const unsigned int c = pre_lds ? lpre[i] : ld_state<AG>(&a.sb_cnt[i]);
       if (pre_lds) lpre[i] = run;
       else a.sb_prefix[i] = run;
       run += c;
@@ -1845,7 +1853,7 @@ __global__ __launch_bounds__(64) void ransac_draw_loop_kernel(RansacLoopArgs a, 
   // (4) the sampled pairs' coordinates, one lookup chain per lane
   for (int t = lane; t < 3 * draws; t += 64) {
     const int pos = dpos[t / 3][t % 3];
-    const int row = all_kept ? pos : select_row(a, pre_lds ? lpre : nullptr, pos);
+    const int row = all_kept ? pos : select_row<AG>(a, pre_lds ? lpre : nullptr, pos);
     const int sl = row >= 0 ? a.inv[row] : -1;
     float4 p = make_float4(0.f, 0.f, 0.f, 0.f), q = p;
     if (sl >= 0) {
@@ -1961,6 +1969,66 @@ __global__ __launch_bounds__(64) void ransac_draw_loop_kernel(RansacLoopArgs a, 
   __builtin_amdgcn_s_waitcnt(0);
   PCLMI_DSTAMP(6);
 #undef PCLMI_DSTAMP
+}
+
+__global__ __launch_bounds__(64) void ransac_draw_loop_kernel(RansacLoopArgs a, int first, int draws) {
+  ransac_draw_body<false>(a, first, draws);
+}
+
+// One rank, first batch of an iteration: the mask words AND the draws in ONE launch (one launch boundary less per
+// iteration).  Every workgroup builds the words of its 1024 rows - nothing to do when every row has a pair, the state
+// of a converging align - and workgroup 0's first wavefront then draws; it waits for the other workgroups' words only
+// when there are any (they depend on nothing, so they always arrive; the wait is bounded all the same).  The words
+// and counts are handed over with agent-scope stores, drained, and an arrival count.
+__global__ __launch_bounds__(kSbRows) void ransac_words_draw_kernel(RansacLoopArgs a, int draws) {
+  if (a.st->done || a.st->hold) return;
+  const bool all_kept = llround(a.sums[a.est ? 27 : 0]) == (long long)a.n_rows;
+  if (!all_kept) {
+    const int row = blockIdx.x * kSbRows + threadIdx.x;
+    bool k = false;
+    if (row < a.n_rows) {
+      const int sl = a.inv[row];
+      k = sl >= 0 && a.keep_slot[sl] != 0;
+    }
+    const unsigned long long w = __ballot(k);
+    __shared__ int c16[kSbRows / 64];
+    if ((threadIdx.x & 63) == 0) {
+      c16[threadIdx.x >> 6] = __popcll(w);
+      st_state<true>(&a.keep_bits[row >> 6], w);  // nsb * 16 words are allocated
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int t = 0;
+      for (int i = 0; i < kSbRows / 64; ++i) t += c16[i];
+      st_state<true>(&a.sb_cnt[blockIdx.x], (unsigned int)t);
+    }
+    drain_stores();
+    __syncthreads();
+    if (threadIdx.x == 0)
+      __hip_atomic_fetch_add((g_u32p)&a.rl->wticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+  if (!all_kept) {
+    const long long t0 = wall_clock64();
+    unsigned int spins = 0;
+    bool ok = true;
+    while (ld_state<true>(&a.rl->wticket) != gridDim.x) {
+      if ((++spins & 63u) == 0u && (unsigned long long)(wall_clock64() - t0) > 500000000ull) {  // 5 s
+        ok = false;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    if (threadIdx.x == 0) st_state<true>(&a.rl->wticket, 0u);
+    if (!ok) {
+      if (threadIdx.x == 0) {
+        a.st->status = PCLMI_ERR_HIP;
+        a.st->done = 1;
+      }
+      return;
+    }
+  }
+  ransac_draw_body<true>(a, 1, draws);
 }
 
 // countWithinDistance of every model of the batch in one pass over the stored source points (masked by keep_slot),
@@ -2489,6 +2557,11 @@ void launch_fitness(const float *d_d2, size_t n, double max_range, double *d_out
 
 void launch_ransac_loop_batch(const RansacLoopArgs &a, int first, int draws, hipStream_t s) {
   if (draws > kRansacBatch) draws = kRansacBatch;
+  static const bool fuse = [] { const char *e = getenv("PCLMI_RANSAC_FUSE_WORDS"); return !(e && e[0] == '0'); }();
+  if (first && a.nsb > 0 && a.comm.world == 1 && fuse) {
+    hipLaunchKernelGGL(ransac_words_draw_kernel, dim3((unsigned)a.nsb), dim3(kSbRows), 0, s, a, draws);
+    return;  // the first batch's models are counted by launch_ransac_loop_first
+  }
   if (first && a.nsb > 0) {
     hipLaunchKernelGGL(ransac_keep_words_kernel, dim3((unsigned)a.nsb), dim3(kSbRows), 0, s, a);
     if (a.comm.world > 1)

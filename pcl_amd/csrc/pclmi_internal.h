@@ -387,6 +387,7 @@ struct RansacLoopState {
   int need_refit;                       // settled, but not by the model the first batch's fused refit sums belong to
   int batches, trials_last;             // diagnostics: batches of this iteration; trials of the last settled one
   unsigned int skipped, ticket;
+  unsigned int wticket, wpad;  // arrivals of the mask-word workgroups of ransac_words_draw_kernel (zero between launches)
   double k, sthr;
   float Tbest[16];
   unsigned long long dbg[12];  // development aid (PCLMI_RANSAC_TICKS=1): wall_clock64 stamps of the last draw kernel
