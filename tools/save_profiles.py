@@ -32,8 +32,8 @@ PMC = {
     ("radius", "prov_sort_kernel"): ("prov_sort", "prof_radius.py 1e6 1e6 3"),
     ("icp", "icp_step_kernel"): ("icp_step", "prof_icp.py 10 (RANSAC off)"),
     ("ransac", "icp_step_kernel"): ("ransac_rs_step", "prof_icp_ransac.py (two default 30-iteration aligns)"),
-    ("ransac", "ransac_keep_words_kernel"): ("ransac_keep_words", "prof_icp_ransac.py"),
-    ("ransac", "ransac_draw_loop_kernel"): ("ransac_draw_loop", "prof_icp_ransac.py"),
+    ("ransac", "ransac_words_draw_kernel"): ("ransac_words_draw", "prof_icp_ransac.py (pair-mask words + the first batch's draws)"),
+    ("ransac", "ransac_draw_loop_kernel"): ("ransac_draw_loop", "prof_icp_ransac.py (the draws of further batches)"),
     ("ransac", "ransac_first_kernel"): ("ransac_first", "prof_icp_ransac.py"),
 }
 for (run, kern), (name, cmd) in PMC.items():
@@ -42,7 +42,7 @@ for (run, kern), (name, cmd) in PMC.items():
         print("missing", src)
         continue
     d = json.load(open(src)).get(kern)
-    if d:
+    if d and d.get("launches_averaged"):
         stamp(d, os.path.join(pr, "%s_%s_pmc.json" % (tag, name)),
               {"kernel": kern, "collected_by": "tools/pmc_kernel.sh (rocprofv3 --pmc, one counter group per run) over tools/" + cmd})
 if os.path.exists(os.path.join(go, "bench.json")):
