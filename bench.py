@@ -789,11 +789,11 @@ def bench_extras(env, tree, target, q_host, q_dev, stream):
         p = capi.icp_default_params()
         p.ransac_iterations, p.max_correspondence_distance = 0, 25.0
         times = {}
-        for iters_pl in (2, 2, 22):
+        for iters_pl in (2, 2, 22, 2, 22, 2, 22):  # best of three each: the set-up (upload, ordering) jitters by a few %
             p.max_iterations = iters_pl
             t0 = time.perf_counter()
             rc, Tpl, _, stpl = capi.icp_align_point_to_plane(t2, src, tn, p)
-            times[iters_pl] = time.perf_counter() - t0
+            times[iters_pl] = min(times.get(iters_pl, 1e9), time.perf_counter() - t0)
         ex["icp_point_to_plane"] = {"workload": "configs[3] clouds, target normals from pclmi_normals (k = 16), "
                                                 "pclmi_icp_align_point_to_plane, RANSAC off, one GPU; per-iteration time "
                                                 "= (22-iteration align - 2-iteration align) / 20, so set-up cancels",
