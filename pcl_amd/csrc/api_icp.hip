@@ -1037,7 +1037,13 @@ int ransac_loop_align(pclmi_icp_ctx *c, const pclmi_icp_params *p, float final_T
     const bool stalled = h.hold != 0;
     while (h.hold && !h.done) {  // the iteration that waits: further batches (ransac.hpp:71-121), then the refit
       if (!hr.settled) {
-        launch_ransac_loop_batch(rb.a, 0, kRansacBatch, s);
+        // as many batches as the rule asks for right now (k only falls as better models turn up: batches past the
+        // point where it settles are no-ops), and the refit behind them - one round trip for the whole iteration
+        // when the estimate holds, instead of one per batch of 64 trials
+        const double want = std::min(hr.k, (double)p->ransac_iterations) - (double)hr.iterations;
+        const int batches = (int)std::max(1.0, std::min(16.0, std::ceil(want / (double)kRansacBatch)));
+        for (int b = 0; b < batches; ++b) launch_ransac_loop_batch(rb.a, 0, kRansacBatch, s);
+        RC(ransac_loop_enqueue(c, rb, p, 0));  // runs only once the rule has settled
         PCLMI_HIP(hipMemcpyAsync(&hr, rb.rl.p, sizeof(hr), hipMemcpyDeviceToHost, s));
         PCLMI_HIP(hipMemcpyAsync(&h, c->state.p, sizeof(h), hipMemcpyDeviceToHost, s));
         PCLMI_HIP(hipStreamSynchronize(s));
