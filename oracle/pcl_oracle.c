@@ -386,8 +386,11 @@ static void knn_level(const orc_tree *t, const float *q, int32_t node, float min
   float dst = dists[f];
   mindist = mindist + cut - dst;
   dists[f] = cut;
-  /* non-strict so that an equal-distance, lower-index candidate is still reached */
-  if (r->n < r->k || mindist <= r->d[r->k - 1]) knn_level(t, q, other, mindist, dists, r);
+  /* non-strict so that an equal-distance, lower-index candidate is still reached; and with a few ulps of slack:
+   * FLANN's incremental `mindist + cut - dst` is rounded three times and can come out an ulp ABOVE the distance of a
+   * point that lies on the cut (duplicated points on either side of a plane: found by tools/stress_search.py), which
+   * would prune a tie the (d2, index) rule has to see.  The leaf tests are exact, so the slack only costs visits. */
+  if (r->n < r->k || mindist * 0.999996f <= r->d[r->k - 1]) knn_level(t, q, other, mindist, dists, r);
   dists[f] = dst;
 }
 
@@ -419,7 +422,7 @@ static void radius_level(const orc_tree *t, const float *q, int32_t node, float 
   float dst = dists[f];
   mindist = mindist + cut - dst;
   dists[f] = cut;
-  if (mindist <= r2) radius_level(t, q, other, mindist, dists, r2, r);
+  if (mindist * 0.999996f <= r2) radius_level(t, q, other, mindist, dists, r2, r); /* slack: see knn_level */
   dists[f] = dst;
 }
 

@@ -662,6 +662,13 @@ __global__ __launch_bounds__(64) void knn_heap_kernel(TreeView t, const float *_
   const int qi = order ? order[slot] : slot;
   const float *p = q + (size_t)qi * q_stride_f;
   const float qx = p[0], qy = p[1], qz = p[2];
+  if (!(isfinite(qx) && isfinite(qy) && isfinite(qz))) {  // as every other k-NN kernel answers a query that is no point
+    for (int j = 0; j < k; ++j) {
+      out_idx[(size_t)qi * k + j] = -1;
+      out_d2[(size_t)qi * k + j] = __builtin_nanf("");
+    }
+    return;
+  }
   unsigned long long *h = heap + slot;  // element e at h[e * nq]
   const size_t S = (size_t)nq;
   int cnt = 0;

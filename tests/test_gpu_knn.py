@@ -326,3 +326,21 @@ def test_k_above_64_in_tiles_of_64(capi, orc, k):
     gi, gd = tb.knn(qb, k)
     oi, od = orc.Tree(big).knn(qb[:3000], k, nthreads=16)
     assert np.array_equal(gi[:3000], oi) and np.array_equal(gd[:3000].view(np.int32), od.view(np.int32))
+
+
+def test_queries_that_are_no_points_at_k_above_64(capi, orc):
+    """Every k-NN kernel answers a non-finite query with (-1, NaN) rows; the heap kernel (k > 64, small batches) once
+    returned real indices with NaN distances (found by tools/stress_search.py)."""
+    pts = util.uniform_cloud(700, 61)
+    tree = capi.Tree(pts)
+    q = util.uniform_cloud(40, 62)
+    q[0] = np.nan
+    q[17, 1] = np.inf
+    good = np.isfinite(q).all(axis=1)
+    for k in (65, 200, 700):
+        gi, gd = tree.knn(q, k)
+        oi, od = orc.knn_brute(pts, q[good], k)
+        assert np.array_equal(gi[good], oi) and np.array_equal(gd[good].view(np.int32), od.view(np.int32))
+        assert (gi[~good] == -1).all() and np.isnan(gd[~good]).all()
+    gi, gd = tree.knn(q[:1], 65)  # a batch of one, and that one no point
+    assert (gi == -1).all() and np.isnan(gd).all()

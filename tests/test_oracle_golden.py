@@ -139,6 +139,24 @@ def test_tree_matches_brute_force_with_ties():
     assert np.array_equal(bo, to) and np.array_equal(bi, ti) and np.array_equal(bd, td)
 
 
+def test_tree_matches_brute_force_on_duplicated_points():
+    # duplicates end up on both sides of a cut; the tree's incremental bound (rounded three times) must not prune the
+    # side that holds the lower index of a tie (found by tools/stress_search.py: 2 of 2002 nearest neighbours differed)
+    rng = np.random.default_rng(5)
+    for seed in range(6):
+        base = rng.uniform(0, 16, (290, 3)).astype(np.float32)
+        pts = base[rng.integers(0, len(base), 2002)]
+        q = (pts[rng.integers(0, len(pts), 2002)] + rng.normal(0, 0.2, (2002, 3))).astype(np.float32)
+        t = orc.Tree(pts)
+        for k in (1, 5):
+            bi, bd = orc.knn_brute(pts, q, k)
+            ti, td = t.knn(q, k, nthreads=4)
+            assert np.array_equal(bi, ti) and np.array_equal(bd, td)
+        bo, bi, bd = orc.radius_brute(pts, q[:300], 0.7)
+        to, ti, td = t.radius(q[:300], 0.7, nthreads=4)
+        assert np.array_equal(bo, to) and np.array_equal(bi, ti) and np.array_equal(bd, td)
+
+
 def test_tree_vs_brute_random_dense_and_radius_variants():
     # recipe of test/test_search.cpp:571-617: 1200 uniform [0,1) points
     pts = util.uniform_cloud(1200, 7)
