@@ -359,6 +359,60 @@ int knn_check(const pclmi_tree *t, const float *d_q, size_t nq, size_t q_stride_
 
 using namespace pclmi;
 
+// rho2[slot] = 0.2401 * (squared distance from the slot's point to its nearest OTHER indexed point) = (0.49 D)^2.
+// A query p with |p - t_j| < 0.49 D_j has t_j as its nearest neighbour, and strictly: every other point t_k is at
+// |p - t_k| >= |t_j - t_k| - |p - t_j| > (1 / 0.49 - 1) |p - t_j| = 1.04 |p - t_j|, a margin of 8 % in the squared
+// distances against the 1e-6 the fp32 evaluations (here, in the step kernel and in the walk it replaces) can be off by.
+// Duplicated points have D = 0: never certified, the walk settles their tie by index as before.
+__global__ void rho_from_nn_kernel(const float4 *__restrict__ slot, size_t n_slots, const float *__restrict__ d2,
+                                   size_t rows, float *__restrict__ rho2) {
+  const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_slots) return;
+  const int idx = __float_as_int(slot[s].w);  // external row; -1 in padded slots
+  float r = 0.f;
+  if (idx >= 0 && (size_t)idx < rows) {
+    const float d = d2[(size_t)idx * 2 + 1];  // [0] is the point itself (or a duplicate of it: then [1] is 0 too)
+    if (d > 0.f && d < 3.0e38f) r = __fmul_rn(0.2401f, d);
+  }
+  rho2[s] = r;
+}
+
+namespace pclmi {
+int tree_ensure_rho(const pclmi_tree *t) {
+  static const bool off = [] {
+    const char *e = getenv("PCLMI_ICP_CERT");
+    return e && e[0] == '0';
+  }();
+  if (off || t->n < 2 || t->rows == 0 || !t->d_cloud) return PCLMI_OK;
+  std::lock_guard<std::mutex> g(t->rho_mu);
+  if (t->d_rho2 || t->rho_tried) return PCLMI_OK;
+  t->rho_tried = true;
+  PCLMI_HIP(hipSetDevice(t->device));
+  const size_t rows = t->rows, n_slots = (size_t)t->M * kLeafSize;
+  DevBuf<int32_t> idx;
+  DevBuf<float> d2;
+  RC(idx.alloc(rows * 2));
+  RC(d2.alloc(rows * 2));
+  float *rho = nullptr;
+  PCLMI_HIP(hipMalloc(&rho, n_slots * sizeof(float)));
+  // rows that are not indexed (non-finite, or outside an index view) are searched too; nothing reads their result
+  int rc = pclmi_knn_dev(t, t->d_cloud, rows, 16, 2, idx.p, d2.p, nullptr);  // waits for its kernels
+  if (!rc) {
+    hipLaunchKernelGGL(rho_from_nn_kernel, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, t->stream,
+                       (const float4 *)t->d_slot, n_slots, d2.p, rows, rho);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
+    if (e != hipSuccess) rc = hip_fail(e, "nearest-other-point radii", __FILE__, __LINE__);
+  }
+  if (rc) {
+    (void)hipFree(rho);
+    return rc;
+  }
+  t->d_rho2 = rho;
+  return PCLMI_OK;
+}
+}  // namespace pclmi
+
 extern "C" {
 
 const char *pclmi_version(void) { return "pclmi 0.1 (gfx950)"; }
@@ -588,12 +642,14 @@ void pclmi_tree_destroy(pclmi_tree *t) {
   if (t->d_leaf) (void)hipFree(t->d_leaf);
   if (t->d_slot) (void)hipFree(t->d_slot);
   if (t->d_cloud) (void)hipFree(t->d_cloud);
+  if (t->d_rho2) (void)hipFree(t->d_rho2);
   if (t->stream) (void)hipStreamDestroy(t->stream);
   if (t->side) (void)hipStreamDestroy(t->side);
   delete t;
 }
 
 size_t pclmi_tree_size(const pclmi_tree *t) { return t ? t->n : 0; }
+
 
 const char *pclmi_knn_kernel_name(const pclmi_tree *t, size_t nq, int k) {
   if (!t || k <= 0) return "";

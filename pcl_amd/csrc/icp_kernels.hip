@@ -763,29 +763,48 @@ __global__ __launch_bounds__(64 * ICP_WPB) __attribute__((amdgpu_waves_per_eu(LO
       vz = __fmul_rn(p.z, az);
     }
     PCLMI_WALK_STAMP(1);
-    unsigned long long best;
+    unsigned long long best = make_key(3.402823466e+38f, 0x7fffffff);
     int bslot = 0;
     float tau0 = __builtin_inff();
     int start_leaf = 0;  // heap id of the previous neighbour's bucket: where the per-lane walk starts
+    // certified: the point is still closer to its previous neighbour than 0.49 x that neighbour's distance to ITS
+    // nearest other point (TreeView::rho2) - then it is the nearest neighbour, strictly, and there is nothing to walk
+    // for.  A converged iteration on a cloud whose noise is small against its spacing certifies nearly every point.
+    bool certified = false;
     if (have_prev && searchable) {
       const int j = nn_slot[slot];
       if (j >= 0) {  // the previous neighbour is an indexed point: its distance bounds the new nearest one
         const float4 o = rows[j];
+        const float rho = t.rho2 ? t.rho2[j] : 0.f;
         tau0 = sq3(vx - o.x, vy - o.y, vz - o.z);
         start_leaf = t.M + j / L;
+        if (tau0 < rho) {
+          certified = true;
+          best = make_key(tau0, __float_as_int(o.w));  // the key the walk would return: same fp32 expression
+          bslot = j;
+        }
       }
     }
     PCLMI_WALK_STAMP(2);
-    const int root = have_prev ? wave_common_root(t, vx, vy, vz, searchable, tau0) : 1;
-    PCLMI_WALK_STAMP(3);
-    if (LANE) {
-      best = lane_nearest(t, vx, vy, vz, searchable, tau0,
-                          reinterpret_cast<float(*)[64]>(far_lds + (size_t)wib * levels * 64), lane, root, bslot,
-                          start_leaf);
-    } else {
-      // wave-uniform walk below the common root; lanes without a previous neighbour (first step, or the point was
-      // not searchable then) have an infinite bound, which only keeps the root at 1
-      best = wave_nearest(t, vx, vy, vz, searchable, lane, have_prev != 0, tau0, root, &bslot);
+    const bool walks = searchable && !certified;
+    if (__any(walks)) {
+      const int root = have_prev ? wave_common_root(t, vx, vy, vz, walks, tau0) : 1;
+      PCLMI_WALK_STAMP(3);
+      unsigned long long wbest;
+      int wslot = 0;
+      if (LANE) {
+        wbest = lane_nearest(t, vx, vy, vz, walks, tau0,
+                             reinterpret_cast<float(*)[64]>(far_lds + (size_t)wib * levels * 64), lane, root, wslot,
+                             start_leaf);
+      } else {
+        // wave-uniform walk below the common root; lanes without a previous neighbour (first step, or the point was
+        // not searchable then) have an infinite bound, which only keeps the root at 1
+        wbest = wave_nearest(t, vx, vy, vz, walks, lane, have_prev != 0, tau0, root, &wslot);
+      }
+      if (!certified) {
+        best = wbest;
+        bslot = wslot;
+      }
     }
     PCLMI_WALK_STAMP(4);
     if (alive) {

@@ -87,6 +87,9 @@ struct TreeView {
                       // buffer compaction stay inside the part of the tree the XCD already holds in L2
   int M;             // number of leaves (>= 1 when n > 0)
   int n;             // number of indexed points
+  const float *rho2; // [M * L] nullable: per bucket slot, 0.2401 x the squared distance from that point to its nearest
+                     // OTHER indexed point (tree_ensure_rho); a query closer than that to the point has it as its one
+                     // nearest neighbour (the ICP step's certificate for "same neighbour as last iteration")
 };
 
 struct Workspace; // per-call scratch (Morton keys, permutations, sort temp), pooled per tree
@@ -116,8 +119,12 @@ struct pclmi_tree {
   mutable double radius_hint = 0.0;  // neighbours per query of the last radius search (sizes the next call's output)
   mutable hipStream_t side = nullptr;
   mutable int n_pipe_ws = 0;  // workspaces created for pipelined calls (a few alternate)
+  // nearest-other-point radii per bucket slot, computed once on the first ICP context of the tree (tree_ensure_rho)
+  mutable std::mutex rho_mu;
+  mutable float *d_rho2 = nullptr;
+  mutable bool rho_tried = false;
 
-  pclmi::TreeView view() const { return pclmi::TreeView{d_box, d_leaf, d_cloud, d_slot, M, (int)n}; }
+  pclmi::TreeView view() const { return pclmi::TreeView{d_box, d_leaf, d_cloud, d_slot, M, (int)n, d_rho2}; }
 };
 
 namespace pclmi {
@@ -211,6 +218,9 @@ int launch_morton_order(const pclmi_tree *t, Workspace *w, const float *d_q, siz
                         size_t q_stride_f, const float *bb_lo, const float *bb_hi, hipStream_t s,
                         const int32_t **d_order, bool stable = false);
 const char *knn_kernel_name(const pclmi_tree *t, size_t nq, int k_eff);
+// Once per tree (first ICP context): the nearest-other-point radius of every bucket slot (TreeView::rho2), from a k = 2
+// search of the tree's own cloud.  A failure leaves the tree without them (the ICP step then walks for every point).
+int tree_ensure_rho(const pclmi_tree *t);
 int launch_knn(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, size_t q_stride_f,
                const int32_t *d_order, int k_eff, int32_t *d_idx, float *d_d2, hipStream_t s);
 // the search fused with the surface-normal plane fit (k-NN neighbourhoods with knn_normals_fused(k_eff))
