@@ -359,56 +359,93 @@ int knn_check(const pclmi_tree *t, const float *d_q, size_t nq, size_t q_stride_
 
 using namespace pclmi;
 
-// rho2[slot] = 0.2401 * (squared distance from the slot's point to its nearest OTHER indexed point) = (0.49 D)^2.
-// A query p with |p - t_j| < 0.49 D_j has t_j as its nearest neighbour, and strictly: every other point t_k is at
-// |p - t_k| >= |t_j - t_k| - |p - t_j| > (1 / 0.49 - 1) |p - t_j| = 1.04 |p - t_j|, a margin of 8 % in the squared
-// distances against the 1e-6 the fp32 evaluations (here, in the step kernel and in the walk it replaces) can be off by.
-// Duplicated points have D = 0: never certified, the walk settles their tie by index as before.
-__global__ void rho_from_nn_kernel(const float4 *__restrict__ slot, size_t n_slots, const float *__restrict__ d2,
-                                   size_t rows, float *__restrict__ rho2) {
+// Certificates for "the nearest neighbour has not changed" (TreeView::cert).  For the point t_j of a bucket slot let
+// D1 <= D2 be its distances to the nearest and second nearest OTHER indexed points.  A query p with |p - t_j| < 0.49 D1
+// has t_j as its nearest neighbour, strictly: every other t_k is at |p - t_k| >= |t_j - t_k| - |p - t_j| >
+// (1 / 0.49 - 1) |p - t_j| = 1.04 |p - t_j| - 8 % in the squared distances against the 1e-6 the fp32 evaluations (here,
+// in the step kernel and in the walk they replace) can be off by.  With |p - t_j| < 0.49 D2 the same holds for every
+// point but the nearest other one, so the answer is the smaller (d2, index) key of those two.  Duplicates of t_j have
+// D1 = 0 (level one never fires; level two then decides between the twins by index, as the walk would); three points
+// in one place have D2 = 0 and always walk.
+#ifndef PCLMI_CERT_FACTOR
+#define PCLMI_CERT_FACTOR 0.2401f  // 0.49^2 (a variant built with 1.0f must fail tests/test_gpu_icp.py's certificate test)
+#endif
+__global__ void slot_of_row_kernel(const float4 *__restrict__ slot, size_t n_slots, size_t rows, int *__restrict__ inv) {
   const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n_slots) return;
   const int idx = __float_as_int(slot[s].w);  // external row; -1 in padded slots
-  float r = 0.f;
-  if (idx >= 0 && (size_t)idx < rows) {
-    const float d = d2[(size_t)idx * 2 + 1];  // [0] is the point itself (or a duplicate of it: then [1] is 0 too)
-    if (d > 0.f && d < 3.0e38f) r = __fmul_rn(0.2401f, d);
+  if (idx >= 0 && (size_t)idx < rows) inv[idx] = (int)s;
+}
+
+__global__ void cert_from_nn_kernel(const float4 *__restrict__ slot, size_t n_slots, const int *__restrict__ nn,
+                                    const float *__restrict__ d2, const int *__restrict__ inv, size_t rows,
+                                    float4 *__restrict__ cert, int levels) {
+  const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_slots) return;
+  const int own = __float_as_int(slot[s].w);
+  float4 r = make_float4(0.f, 0.f, __int_as_float(0), 0.f);
+  if (own >= 0 && (size_t)own < rows) {
+    int i[3];
+    float d[3];
+    for (int u = 0; u < 3; ++u) {
+      i[u] = nn[(size_t)own * 3 + u];
+      d[u] = d2[(size_t)own * 3 + u];
+    }
+    // the point itself is one of the three (at distance 0) unless three or more points share its place
+    const int self = i[0] == own ? 0 : i[1] == own ? 1 : i[2] == own ? 2 : -1;
+    if (self >= 0) {
+      const int a = self == 0 ? 1 : 0, b = self == 2 ? 1 : 2;
+      const float D1 = d[a], D2 = d[b];
+      const int k1 = i[a];
+      if (k1 >= 0 && (size_t)k1 < rows && D2 > 0.f && D2 < 3.0e38f && D1 >= 0.f) {
+        r.x = __fmul_rn(PCLMI_CERT_FACTOR, D1);
+        r.y = levels >= 2 ? __fmul_rn(PCLMI_CERT_FACTOR, D2) : r.x;
+        r.z = __int_as_float(inv[k1]);
+      }
+    }
   }
-  rho2[s] = r;
+  cert[s] = r;
 }
 
 namespace pclmi {
-int tree_ensure_rho(const pclmi_tree *t) {
-  static const bool off = [] {
+int tree_ensure_cert(const pclmi_tree *t) {
+  // PCLMI_ICP_CERT=0: no certificates (every point walks), =1: the first level only (development switches)
+  static const int levels = [] {
     const char *e = getenv("PCLMI_ICP_CERT");
-    return e && e[0] == '0';
+    return e ? atoi(e) : 2;
   }();
-  if (off || t->n < 2 || t->rows == 0 || !t->d_cloud) return PCLMI_OK;
-  std::lock_guard<std::mutex> g(t->rho_mu);
-  if (t->d_rho2 || t->rho_tried) return PCLMI_OK;
-  t->rho_tried = true;
+  const bool off = levels <= 0;
+  if (off || t->n < 3 || t->rows == 0 || !t->d_cloud) return PCLMI_OK;
+  std::lock_guard<std::mutex> g(t->cert_mu);
+  if (t->d_cert || t->cert_tried) return PCLMI_OK;
+  t->cert_tried = true;
   PCLMI_HIP(hipSetDevice(t->device));
   const size_t rows = t->rows, n_slots = (size_t)t->M * kLeafSize;
-  DevBuf<int32_t> idx;
+  DevBuf<int32_t> idx, inv;
   DevBuf<float> d2;
-  RC(idx.alloc(rows * 2));
-  RC(d2.alloc(rows * 2));
-  float *rho = nullptr;
-  PCLMI_HIP(hipMalloc(&rho, n_slots * sizeof(float)));
+  RC(idx.alloc(rows * 3));
+  RC(d2.alloc(rows * 3));
+  RC(inv.alloc(rows));
+  float *cert = nullptr;
+  PCLMI_HIP(hipMalloc(&cert, n_slots * sizeof(float4)));
   // rows that are not indexed (non-finite, or outside an index view) are searched too; nothing reads their result
-  int rc = pclmi_knn_dev(t, t->d_cloud, rows, 16, 2, idx.p, d2.p, nullptr);  // waits for its kernels
+  int rc = pclmi_knn_dev(t, t->d_cloud, rows, 16, 3, idx.p, d2.p, nullptr);  // waits for its kernels
   if (!rc) {
-    hipLaunchKernelGGL(rho_from_nn_kernel, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, t->stream,
-                       (const float4 *)t->d_slot, n_slots, d2.p, rows, rho);
-    hipError_t e = hipGetLastError();
+    const unsigned blocks = (unsigned)((n_slots + 255) / 256);
+    hipError_t e = hipMemsetAsync(inv.p, 0, rows * sizeof(int32_t), t->stream);
+    hipLaunchKernelGGL(slot_of_row_kernel, dim3(blocks), dim3(256), 0, t->stream, (const float4 *)t->d_slot, n_slots,
+                       rows, inv.p);
+    hipLaunchKernelGGL(cert_from_nn_kernel, dim3(blocks), dim3(256), 0, t->stream, (const float4 *)t->d_slot, n_slots,
+                       idx.p, d2.p, inv.p, rows, (float4 *)cert, levels);
+    if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
-    if (e != hipSuccess) rc = hip_fail(e, "nearest-other-point radii", __FILE__, __LINE__);
+    if (e != hipSuccess) rc = hip_fail(e, "nearest-other-point certificates", __FILE__, __LINE__);
   }
   if (rc) {
-    (void)hipFree(rho);
+    (void)hipFree(cert);
     return rc;
   }
-  t->d_rho2 = rho;
+  t->d_cert = cert;
   return PCLMI_OK;
 }
 }  // namespace pclmi
@@ -642,7 +679,7 @@ void pclmi_tree_destroy(pclmi_tree *t) {
   if (t->d_leaf) (void)hipFree(t->d_leaf);
   if (t->d_slot) (void)hipFree(t->d_slot);
   if (t->d_cloud) (void)hipFree(t->d_cloud);
-  if (t->d_rho2) (void)hipFree(t->d_rho2);
+  if (t->d_cert) (void)hipFree(t->d_cert);
   if (t->stream) (void)hipStreamDestroy(t->stream);
   if (t->side) (void)hipStreamDestroy(t->side);
   delete t;

@@ -274,7 +274,7 @@ int pclmi_icp_begin_sharded(const pclmi_tree *target, const float *src, size_t n
   PCLMI_CHECK(n_src < ((size_t)1 << 31), PCLMI_ERR_UNSUPPORTED, "more than 2^31-1 source points");
   PCLMI_CHECK(target->n > 0, PCLMI_ERR_INVALID, "the target tree is empty");
   PCLMI_HIP(hipSetDevice(target->device));
-  (void)tree_ensure_rho(target);  // once per tree; without the radii the step walks for every point (same results)
+  (void)tree_ensure_cert(target);  // once per tree; without the certificates the step walks for every point (same results)
   pclmi_icp_ctx *c = new pclmi_icp_ctx();
   c->tree = target;
   c->n = n_src;

@@ -743,12 +743,17 @@ __global__ __launch_bounds__(64 * ICP_WPB) __attribute__((amdgpu_waves_per_eu(LO
   float dc = 0.f, prev = 0.f;
   if (wave_live) {
     const bool alive = slot < n;
+    bool moved = false;
+    int j_prev = -1;      // the three per-point loads go out together: one round trip instead of three in a row
+    float d_prev = 0.f;
     if (alive) {
+      if (have_prev) j_prev = nn_slot[slot];
+      d_prev = dist[slot];
       p = pts[slot];
       if (apply && finite3(p)) {
         p = apply_xf(T, p);
-        pts[slot] = p;
-      }
+        moved = true;  // stored with the results below: a store up here sits in the in-order memory counter in front
+      }                //  of every load of the search, whose first wait would then also wait for the write's round trip
     }
     const bool searchable = alive && finite3(p);
     if (!searchable) p.x = p.y = p.z = __builtin_nanf("");
@@ -767,21 +772,33 @@ __global__ __launch_bounds__(64 * ICP_WPB) __attribute__((amdgpu_waves_per_eu(LO
     int bslot = 0;
     float tau0 = __builtin_inff();
     int start_leaf = 0;  // heap id of the previous neighbour's bucket: where the per-lane walk starts
-    // certified: the point is still closer to its previous neighbour than 0.49 x that neighbour's distance to ITS
-    // nearest other point (TreeView::rho2) - then it is the nearest neighbour, strictly, and there is nothing to walk
-    // for.  A converged iteration on a cloud whose noise is small against its spacing certifies nearly every point.
+    // certified: the point is still closer to its previous neighbour t_j than 0.49 x the distance from t_j to ITS
+    // nearest other point - then t_j is the nearest neighbour, strictly - or than 0.49 x the distance to its SECOND
+    // nearest other point - then it is t_j or that nearest other point (TreeView::cert): nothing to walk for.  A
+    // converged iteration on a cloud whose noise is small against its spacing certifies nearly every point.
     bool certified = false;
+    int prev_j = -1;
     if (have_prev && searchable) {
-      const int j = nn_slot[slot];
+      const int j = j_prev;
       if (j >= 0) {  // the previous neighbour is an indexed point: its distance bounds the new nearest one
         const float4 o = rows[j];
-        const float rho = t.rho2 ? t.rho2[j] : 0.f;
+        const float4 c = t.cert ? reinterpret_cast<const float4 *>(t.cert)[j] : make_float4(0.f, 0.f, 0.f, 0.f);
         tau0 = sq3(vx - o.x, vy - o.y, vz - o.z);
         start_leaf = t.M + j / L;
-        if (tau0 < rho) {
+        if (tau0 < (t.cert_levels >= 2 ? c.y : c.x)) {
           certified = true;
+          prev_j = j;
           best = make_key(tau0, __float_as_int(o.w));  // the key the walk would return: same fp32 expression
           bslot = j;
+          if (!(tau0 < c.x)) {  // the nearest other point may have come closer
+            const int k = __float_as_int(c.z);
+            const float4 o2 = rows[k];
+            const unsigned long long key2 = make_key(sq3(vx - o2.x, vy - o2.y, vz - o2.z), __float_as_int(o2.w));
+            if (key2 < best) {
+              best = key2;
+              bslot = k;
+            }
+          }
         }
       }
     }
@@ -808,14 +825,17 @@ __global__ __launch_bounds__(64 * ICP_WPB) __attribute__((amdgpu_waves_per_eu(LO
     }
     PCLMI_WALK_STAMP(4);
     if (alive) {
+      if (moved) pts[slot] = p;
       const int idx = searchable ? (int)(unsigned int)(best & 0xffffffffull) : -1;
       const float d = searchable ? __uint_as_float((unsigned int)(best >> 32)) : __builtin_nanf("");
-      nn_idx[slot] = idx;
-      nn_slot[slot] = searchable ? bslot : -1;
+      if (!(certified && bslot == prev_j)) {  // (a certified point that kept its neighbour has both in place)
+        nn_idx[slot] = idx;
+        nn_slot[slot] = searchable ? bslot : -1;
+      }
       if (RS) keep_slot[slot] = (searchable && (double)d < thr2) ? 1 : 0;
       if (searchable) {
         dc = fminf(d, thr2f);  // icp.hpp:101
-        prev = dist[slot];
+        prev = d_prev;
         dist[slot] = dc;
         counted = true;
         if ((double)d < thr2) {  // strict, icp.hpp:93
@@ -2401,9 +2421,16 @@ void launch_icp_step(const pclmi_tree *t, float4 *d_pts, size_t n, bool apply, c
   const size_t lds_bytes = (size_t)ICP_WPB * levels * 64 * sizeof(float);
   const bool scl = d_raw_tgt != nullptr;    // searches in a rescaled space (api_icp.hip refuses it with the plane loop)
   const bool loop = loop_iters > 1;  // the caller has checked icp_loop_fits() and set tail.loopbox
+  // The second certificate costs the points that need it one more dependent gather.  Up to ~0.26M points (every
+  // wavefront resident at once; the resident loop's range) that beats the walk it replaces by far (125k-point shard:
+  // 26.4 -> 18.8 us per converged iteration); on grids of several passes of wavefronts it measured SLOWER than walking
+  // for those few points (1M points: 51.4 us with the first certificate alone, 58.9 with both; 500k: 35.6 / 37.2).
+  static const int force_levels = [] { const char *e = getenv("PCLMI_ICP_CERT_LEVELS"); return e ? atoi(e) : 0; }();
+  TreeView view = t->view();
+  view.cert_levels = force_levels ? force_levels : (blocks <= 1024 ? 2 : 1);
 #define PCLMI_STEP_LAUNCH(LANE_, EST_, RS_, SC_, LDS_) PCLMI_STEP_LAUNCH5(LANE_, EST_, RS_, SC_, false, LDS_)
 #define PCLMI_STEP_LAUNCH5(LANE_, EST_, RS_, SC_, LOOP_, LDS_)                                                              \
-  hipLaunchKernelGGL((icp_step_kernel<LANE_, EST_, RS_, SC_, LOOP_>), dim3(blocks), dim3(64 * ICP_WPB), LDS_, s, t->view(), d_pts, \
+  hipLaunchKernelGGL((icp_step_kernel<LANE_, EST_, RS_, SC_, LOOP_>), dim3(blocks), dim3(64 * ICP_WPB), LDS_, s, view, d_pts, \
                      (int)n, apply ? 1 : 0, T, (float)thr2, thr2, d_nn, d_nn_slot, d_dist, origin[0], origin[1],        \
                      origin[2], d_partials, (const IcpDevState *)st, levels, have_prev ? 1 : 0, tail, d_tn_slot,        \
                      d_src_skip, d_keep_slot, d_tq, d_raw_tgt, sc[0], sc[1], sc[2], loop_iters)

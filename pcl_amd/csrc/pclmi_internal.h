@@ -87,9 +87,12 @@ struct TreeView {
                       // buffer compaction stay inside the part of the tree the XCD already holds in L2
   int M;             // number of leaves (>= 1 when n > 0)
   int n;             // number of indexed points
-  const float *rho2; // [M * L] nullable: per bucket slot, 0.2401 x the squared distance from that point to its nearest
-                     // OTHER indexed point (tree_ensure_rho); a query closer than that to the point has it as its one
-                     // nearest neighbour (the ICP step's certificate for "same neighbour as last iteration")
+  const float *cert; // [M * L][4] nullable (tree_ensure_cert): per bucket slot j, with D1 <= D2 the distances from that
+                     // point to its nearest and second nearest OTHER indexed points: (0.2401 D1^2, 0.2401 D2^2, bucket
+                     // slot of the nearest other point as int bits, 0).  A query within 0.49 D1 of t_j has t_j as its one
+                     // nearest neighbour; within 0.49 D2, t_j or that nearest other point - the ICP step's certificates
+                     // for "same neighbour as last iteration", which replace the walk
+  int cert_levels;   // 2: both certificates; 1: the first only (launch_icp_step: grids beyond one resident pass)
 };
 
 struct Workspace; // per-call scratch (Morton keys, permutations, sort temp), pooled per tree
@@ -119,12 +122,13 @@ struct pclmi_tree {
   mutable double radius_hint = 0.0;  // neighbours per query of the last radius search (sizes the next call's output)
   mutable hipStream_t side = nullptr;
   mutable int n_pipe_ws = 0;  // workspaces created for pipelined calls (a few alternate)
-  // nearest-other-point radii per bucket slot, computed once on the first ICP context of the tree (tree_ensure_rho)
-  mutable std::mutex rho_mu;
-  mutable float *d_rho2 = nullptr;
-  mutable bool rho_tried = false;
+  // nearest-other-point certificates per bucket slot, computed once on the first ICP context of the tree
+  // (tree_ensure_cert)
+  mutable std::mutex cert_mu;
+  mutable float *d_cert = nullptr;
+  mutable bool cert_tried = false;
 
-  pclmi::TreeView view() const { return pclmi::TreeView{d_box, d_leaf, d_cloud, d_slot, M, (int)n, d_rho2}; }
+  pclmi::TreeView view() const { return pclmi::TreeView{d_box, d_leaf, d_cloud, d_slot, M, (int)n, d_cert, 2}; }
 };
 
 namespace pclmi {
@@ -218,9 +222,10 @@ int launch_morton_order(const pclmi_tree *t, Workspace *w, const float *d_q, siz
                         size_t q_stride_f, const float *bb_lo, const float *bb_hi, hipStream_t s,
                         const int32_t **d_order, bool stable = false);
 const char *knn_kernel_name(const pclmi_tree *t, size_t nq, int k_eff);
-// Once per tree (first ICP context): the nearest-other-point radius of every bucket slot (TreeView::rho2), from a k = 2
-// search of the tree's own cloud.  A failure leaves the tree without them (the ICP step then walks for every point).
-int tree_ensure_rho(const pclmi_tree *t);
+// Once per tree (first ICP context): the nearest-other-point certificates of every bucket slot (TreeView::cert), from a
+// k = 3 search of the tree's own cloud.  A failure leaves the tree without them (the ICP step then walks for every
+// point; same results).
+int tree_ensure_cert(const pclmi_tree *t);
 int launch_knn(const pclmi_tree *t, Workspace *w, const float *d_q, size_t nq, size_t q_stride_f,
                const int32_t *d_order, int k_eff, int32_t *d_idx, float *d_d2, hipStream_t s);
 // the search fused with the surface-normal plane fit (k-NN neighbourhoods with knn_normals_fused(k_eff))

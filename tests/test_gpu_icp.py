@@ -475,3 +475,26 @@ def test_observed_align_reports_every_iteration(capi, orc, ransac, plane):
         idx, d2 = tt.knn(np.nan_to_num(prev), 1)
         keep = (d2[:, 0] < 4.0) & np.isfinite(prev).all(axis=1)
         assert np.array_equal(np.flatnonzero(keep), seen[-1][2]) and np.array_equal(idx[keep, 0], seen[-1][3])
+
+
+def test_certificates_change_nothing(capi, tmp_path):
+    """The step's "same neighbour as last iteration" certificates (TreeView::cert: a point within 0.49 x the distance
+    from its previous neighbour to that neighbour's nearest / second nearest other point) replace the walk, never the
+    answer: every align of tests/icp_cert_worker.py - clean and noisy surfaces, a target with twins and triplets, a
+    lattice of equal distances; RANSAC off and on, the sharded context per launch and as one resident launch,
+    point-to-plane - is bit-identical to a process that runs without them (PCLMI_ICP_CERT=0)."""
+    import os
+    import subprocess
+    import sys
+    from tests import icp_cert_worker
+    here = icp_cert_worker.run(capi)
+    path = str(tmp_path / "nocert.npz")
+    env = dict(os.environ, PCLMI_ICP_CERT="0")
+    subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "icp_cert_worker.py"), path], env=env,
+                   check=True, timeout=300)
+    there = np.load(path)
+    assert set(there.files) == set(here)
+    for k in sorted(here):
+        assert np.array_equal(np.asarray(here[k]), there[k], equal_nan=True), k
+    # the certificates did fire: the clean surface's converged iterations pair every point
+    assert here["surface_0_stats"][3] == here["surface_1_stats"][3] > 0

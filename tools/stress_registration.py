@@ -61,6 +61,12 @@ while time.time() < t_end:
     # ---- clouds
     nt = int(rng.choice([5, 60, 400, 3000, 20000])) + int(rng.integers(0, 7))
     tgt = bench.surface_cloud(max(nt, 50), int(rng.integers(1 << 30)))[:nt]
+    variant = rng.random()
+    if variant < 0.25:  # twins and triplets: the walk's tie rule (lowest index) against the certificates' 
+        tgt = np.concatenate([tgt, tgt[rng.integers(0, nt, nt // 2)], tgt[rng.integers(0, nt, nt // 5)]])[rng.permutation(nt + nt // 2 + nt // 5)]
+        nt = len(tgt)
+    elif variant < 0.4:  # a lattice: equal distances everywhere
+        tgt = (rng.integers(0, 12, (nt, 3)) * 4).astype(np.float32)
     ext = float(np.abs(tgt).max())
     T0 = bench.rigid(float(rng.uniform(0.2, 3.0)), rng.normal(size=3), rng.normal(size=3) * 0.01 * ext)
     sel = rng.permutation(nt)[: max(3, int(nt * rng.uniform(0.3, 1.0)))]
@@ -84,7 +90,10 @@ while time.time() < t_end:
         fail("fitness_score %r / %r" % (fg, fo), src=src, tgt=tgt, T=T0)
     cases["estimators"] += 1
     # ---- normals
-    if nt >= 20:
+    # (not on the lattice: a neighbourhood with a REPEATED smallest eigenvalue has no normal; the reference's closed-form
+    # eigenvector - cross products of the rows of A - lambda I - comes out 0/0 = NaN there, the library returns one of
+    # the valid directions: parity unpinned)
+    if nt >= 20 and not (0.25 <= variant < 0.4):
         otree = orc.Tree(tgt)
         qn = tgt[rng.integers(0, nt, min(nt, 2000))]
         k = int(rng.choice([3, 5, 10, 16, 20, 32, 40]))
@@ -92,7 +101,7 @@ while time.time() < t_end:
         g = capi.normals(tree, qn, k=k, viewpoint=vp)
         o = orc.normals(otree, qn, k=k, viewpoint=vp, nthreads=8)
         ok = np.isfinite(o).all(axis=1) & np.isfinite(g).all(axis=1)
-        if not np.array_equal(np.isfinite(o).all(axis=1), np.isfinite(g).all(axis=1)):
+        if variant >= 0.4 and not np.array_equal(np.isfinite(o).all(axis=1), np.isfinite(g).all(axis=1)):  # (twins: degenerate too)
             fail("normals finite rows k %d" % k, tgt=tgt, q=qn, k=k)
         # the direction: against numpy's fp64 eigenvector of the same neighbours (the oracle restates the reference's
         # fp32 one-pass covariance, whose cancellation at coordinates ~1e3 moves well-conditioned normals by 1e-3 and
@@ -127,8 +136,18 @@ while time.time() < t_end:
         rco, To, outo, sto = orc.icp_align(src, tgt, po, nthreads=8)
         if (rc == 0) != (rco == 0):
             fail("icp status %d / %d" % (rc, rco), src=src, tgt=tgt, mcd=mcd)
-        if rc == 0 and (st.iterations != sto.iterations or st.last_correspondences != sto.last_correspondences or
-                        st.converged != sto.converged or np.abs(T - To).max() > 2e-5 + 2e-6 * ext):
+        # (a handful of pairs: rank-deficient sums, no unique rotation - the two sides part ways, legitimately)
+        few = min(st.last_correspondences, sto.last_correspondences) < 10
+        gi0, gd0 = tree.knn(src, 1)
+        k0 = gd0[:, 0].astype(np.float64) < mcd * mcd
+        if k0.sum() >= 10:
+            S0, T0p = src[k0].astype(np.float64), tgt[gi0[k0, 0]].astype(np.float64)
+            sv = np.linalg.svd((S0 - S0.mean(0)).T @ (T0p - T0p.mean(0)))[1]
+            few = few or sv[1] < 1e-4 * sv[0]  # (the rotation needs two directions)
+        else:
+            few = True
+        if rc == 0 and not few and (st.iterations != sto.iterations or st.last_correspondences != sto.last_correspondences or
+                                    st.converged != sto.converged or np.abs(T - To).max() > 2e-5 + 2e-6 * ext):
             fail("icp n %d mcd %g: it %d/%d pairs %d/%d conv %d/%d dT %g (ext %g)" % (
                 len(src), mcd, st.iterations, sto.iterations, st.last_correspondences, sto.last_correspondences,
                 st.converged, sto.converged, np.abs(T - To).max(), ext), src=src, tgt=tgt, mcd=mcd)
