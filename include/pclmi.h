@@ -369,6 +369,11 @@ int pclmi_fitness_score(const pclmi_tree *target, const float *src, size_t n_src
 /* sums layout: [0] n_pairs, [1..3] sum s, [4..6] sum t, [7..15] sum s t' (row-major),
  * [16] sum min(d2, thr2) over ALL points, [17] sum (d_now - d_prev) over ALL points,
  * [18] n_points, [19..23] reserved (zero). */
+/* The first ICP context (or align) of a tree searches the tree's cloud against itself once (k = 3) and keeps, per
+ * indexed point, 16 bytes of "same neighbour as last iteration" certificates: a source point within 0.49 x the
+ * distance from its previous neighbour to that neighbour's nearest (second nearest) other point provably still has
+ * that neighbour (or that nearest other point) as its nearest one, and the step skips the tree walk for it - the
+ * reference's answer (icp.hpp:84-102) by a shorter route, bit-identical state (PCLMI_ICP_CERT=0 switches it off). */
 typedef struct pclmi_icp_ctx pclmi_icp_ctx;
 int pclmi_icp_begin(const pclmi_tree *target, const float *src, size_t n_src, size_t stride_bytes,
                     const float *guess, pclmi_icp_ctx **out);
