@@ -1,5 +1,5 @@
 """A few device-resident ICP iterations on bench.py's configs[3] data, for rocprofv3 (development helper).
-usage: prof_icp.py [iterations] [n]"""
+usage: prof_icp.py [iterations] [n] [converged]   (converged: start from the true transform - steady iterations only)"""
 import os
 import sys
 
@@ -19,7 +19,7 @@ src = tgt[rng.permutation(n)] + rng.normal(0, 0.1, (n, 3)).astype(np.float32)
 Ti = np.linalg.inv(T0)
 src = (src.astype(np.float64) @ Ti[:3, :3].T + Ti[:3, 3]).astype(np.float32)
 tree = capi.Tree(tgt)
-ctx = capi.IcpShard(tree, src)
+ctx = capi.IcpShard(tree, src, guess=T0 if len(sys.argv) > 3 and sys.argv[3] == "converged" else None)
 ctx.run_dev(25.0, iters)
 rc, T, st = ctx.state()
 print("iterations", st.iterations, "pairs", st.last_correspondences, "err", float(np.abs(T - T0).max()))
