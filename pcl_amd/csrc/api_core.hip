@@ -419,7 +419,7 @@ int tree_ensure_cert(const pclmi_tree *t) {
   // and the k = 3 search with its two waits (~0.15 ms) would be a fifth of a whole bun0 -> bun4 align
   if (off || t->n < 4096 || t->rows == 0 || !t->d_cloud) return PCLMI_OK;
   std::lock_guard<std::mutex> g(t->cert_mu);
-  if (t->d_cert || t->cert_tried) return PCLMI_OK;
+  if (t->d_cert.load() || t->cert_tried) return PCLMI_OK;
   t->cert_tried = true;
   PCLMI_HIP(hipSetDevice(t->device));
   const size_t rows = t->rows, n_slots = (size_t)t->M * kLeafSize;
@@ -447,7 +447,7 @@ int tree_ensure_cert(const pclmi_tree *t) {
     (void)hipFree(cert);
     return rc;
   }
-  t->d_cert = cert;
+  t->d_cert.store(cert, std::memory_order_release);
   return PCLMI_OK;
 }
 }  // namespace pclmi
@@ -681,7 +681,7 @@ void pclmi_tree_destroy(pclmi_tree *t) {
   if (t->d_leaf) (void)hipFree(t->d_leaf);
   if (t->d_slot) (void)hipFree(t->d_slot);
   if (t->d_cloud) (void)hipFree(t->d_cloud);
-  if (t->d_cert) (void)hipFree(t->d_cert);
+  if (t->d_cert.load()) (void)hipFree(t->d_cert.load());
   if (t->stream) (void)hipStreamDestroy(t->stream);
   if (t->side) (void)hipStreamDestroy(t->side);
   delete t;

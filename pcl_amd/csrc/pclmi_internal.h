@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -125,10 +126,10 @@ struct pclmi_tree {
   // nearest-other-point certificates per bucket slot, computed once on the first ICP context of the tree
   // (tree_ensure_cert)
   mutable std::mutex cert_mu;
-  mutable float *d_cert = nullptr;
+  mutable std::atomic<float *> d_cert{nullptr};  // published once, read by every launch's view()
   mutable bool cert_tried = false;
 
-  pclmi::TreeView view() const { return pclmi::TreeView{d_box, d_leaf, d_cloud, d_slot, M, (int)n, d_cert, 2}; }
+  pclmi::TreeView view() const { return pclmi::TreeView{d_box, d_leaf, d_cloud, d_slot, M, (int)n, d_cert.load(std::memory_order_acquire), 2}; }
 };
 
 namespace pclmi {
