@@ -311,8 +311,8 @@ int pclmi_icp_begin_sharded(const pclmi_tree *target, const float *src, size_t n
       (rc = c->sums.alloc(kIcpMaxSums)))
     return fail(rc);
   c->groups = icp_step_groups(n_src);
-  if ((rc = c->gpart.alloc((size_t)c->groups * kIcpMaxSums)) || (rc = c->tickets.alloc(c->groups + 1))) return fail(rc);
-  if (hipMemsetAsync(c->tickets.p, 0, (c->groups + 1) * sizeof(unsigned int), c->stream) != hipSuccess)
+  if ((rc = c->gpart.alloc((size_t)c->groups * kIcpMaxSums)) || (rc = c->tickets.alloc((size_t)c->groups * kTicketStride + 1))) return fail(rc);
+  if (hipMemsetAsync(c->tickets.p, 0, ((size_t)c->groups * kTicketStride + 1) * sizeof(unsigned int), c->stream) != hipSuccess)
     return fail(hip_fail(hipGetLastError(), "memset", __FILE__, __LINE__));
   {
     WsGuard g(target, c->stream);
@@ -434,7 +434,7 @@ static int icp_step_enqueue(pclmi_icp_ctx *c, double max_correspondence_distance
   IcpTail tail;
   tail.gpart = c->gpart.p;
   tail.gticket = c->tickets.p;
-  tail.ticket = c->tickets.p + c->groups;
+  tail.ticket = c->tickets.p + (size_t)c->groups * kTicketStride;
   tail.sums_out = d_sums;
   tail.st = c->dev_mode ? c->state.p : nullptr;
   tail.solve = (fused && !d_keep_slot) ? 1 : 0;  // the RANSAC loop's step: the refit launch solves
@@ -1000,7 +1000,7 @@ int ransac_loop_enqueue(pclmi_icp_ctx *c, RansacLoopBufs &rb, const pclmi_icp_pa
   IcpTail tail;
   tail.gpart = c->gpart.p;
   tail.gticket = c->tickets.p;
-  tail.ticket = c->tickets.p + c->groups;
+  tail.ticket = c->tickets.p + (size_t)c->groups * kTicketStride;
   tail.sums_out = rb.sums2.p;
   tail.st = c->state.p;
   tail.solve = 1;

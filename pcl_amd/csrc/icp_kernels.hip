@@ -348,7 +348,7 @@ __device__ __forceinline__ void icp_step_tail(const IcpTail &tail, double *__res
   const int g = blockIdx.x / ICP_GROUP;
   const int gsize = min(ICP_GROUP, nblk - g * ICP_GROUP);
   if (tid == 0) {
-    const unsigned int t = __hip_atomic_fetch_add((g_u32p)&tail.gticket[g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned int t = __hip_atomic_fetch_add((g_u32p)&tail.gticket[(size_t)g * kTicketStride], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = (t == (unsigned int)(gsize - 1)) ? 1 : 0;
   }
   __syncthreads();
@@ -364,7 +364,7 @@ __device__ __forceinline__ void icp_step_tail(const IcpTail &tail, double *__res
   drain_stores();
   __syncthreads();
   if (tid == 0) {
-    __hip_atomic_store((g_u32p)&tail.gticket[g], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
+    __hip_atomic_store((g_u32p)&tail.gticket[(size_t)g * kTicketStride], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
     const unsigned int t = __hip_atomic_fetch_add((g_u32p)tail.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = (t == (unsigned int)(tail.ngroups - 1)) ? 1 : 0;
   }
@@ -2421,13 +2421,10 @@ void launch_icp_step(const pclmi_tree *t, float4 *d_pts, size_t n, bool apply, c
   const size_t lds_bytes = (size_t)ICP_WPB * levels * 64 * sizeof(float);
   const bool scl = d_raw_tgt != nullptr;    // searches in a rescaled space (api_icp.hip refuses it with the plane loop)
   const bool loop = loop_iters > 1;  // the caller has checked icp_loop_fits() and set tail.loopbox
-  // The second certificate costs the points that need it one more dependent gather.  Up to ~0.26M points (every
-  // wavefront resident at once; the resident loop's range) that beats the walk it replaces by far (125k-point shard:
-  // 26.4 -> 18.8 us per converged iteration); on grids of several passes of wavefronts it measured SLOWER than walking
-  // for those few points (1M points: 51.4 us with the first certificate alone, 58.9 with both; 500k: 35.6 / 37.2).
+  // (PCLMI_ICP_CERT_LEVELS=1: the first certificate only, for A/B runs)
   static const int force_levels = [] { const char *e = getenv("PCLMI_ICP_CERT_LEVELS"); return e ? atoi(e) : 0; }();
   TreeView view = t->view();
-  view.cert_levels = force_levels ? force_levels : (blocks <= 1024 ? 2 : 1);
+  view.cert_levels = force_levels ? force_levels : 2;
 #define PCLMI_STEP_LAUNCH(LANE_, EST_, RS_, SC_, LDS_) PCLMI_STEP_LAUNCH5(LANE_, EST_, RS_, SC_, false, LDS_)
 #define PCLMI_STEP_LAUNCH5(LANE_, EST_, RS_, SC_, LOOP_, LDS_)                                                              \
   hipLaunchKernelGGL((icp_step_kernel<LANE_, EST_, RS_, SC_, LOOP_>), dim3(blocks), dim3(64 * ICP_WPB), LDS_, s, view, d_pts, \

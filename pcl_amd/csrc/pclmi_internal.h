@@ -293,9 +293,13 @@ struct IcpDevState {
 };
 // What the workgroup that finishes a step's reduction goes on to do (icp_kernels.hip icp_step_tail): group sums,
 // the launch's sums, the exchange with the other ranks (comm.world > 1), the solve (solve != 0, needs st).
+// Arrival tickets of different groups sit kTicketStride words (4 KB) apart.  Device-scope atomics execute at the memory
+// side, one channel per address range: packed into four cache lines, the ~4000 arrivals of a 1M-point step queued up
+// behind each other whenever the workgroups finished together (which the certificates make them do): +6 us per step.
+constexpr size_t kTicketStride = 1024;
 struct IcpTail {
   double *gpart = nullptr;          // [sums][ngroups] group sums
-  unsigned int *gticket = nullptr;  // [ngroups] arrival tickets, zero between launches
+  unsigned int *gticket = nullptr;  // [ngroups * kTicketStride] arrival tickets (one per group), zero between launches
   unsigned int *ticket = nullptr;   // groups finished, zero between launches
   double *sums_out = nullptr;       // [PCLMI_ICP_NSUMS or _PLANE (+ 8 in the RANSAC loop)] the launch's (all-reduced) sums
   IcpDevState *st = nullptr;
