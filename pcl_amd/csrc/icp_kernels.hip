@@ -308,10 +308,11 @@ constexpr int ICP_GROUP = 64;  // workgroups per reduction group
 
 // Sum of column `col` over `cnt` entries spaced 1 apart, by the 8 lanes of one aligned lane group (r = lane & 7):
 // entries r, r + 8, ... in ascending order, then a fixed butterfly.  The order depends on cnt only.
-__device__ __forceinline__ double tail_column_sum(const double *col_base, int cnt, int r, bool active) {
+__device__ __forceinline__ double tail_column_sum(const double *col_base, int cnt, int r, bool active,
+                                                  size_t stride = 1) {
   double s = 0.0;
   if (active)
-    for (int i = r; i < cnt; i += 8) s += ld_agent(col_base + i);
+    for (int i = r; i < cnt; i += 8) s += ld_agent(col_base + (size_t)i * stride);
   s += __shfl_xor(s, 4);
   s += __shfl_xor(s, 2);
   s += __shfl_xor(s, 1);
@@ -340,8 +341,9 @@ __device__ __forceinline__ void icp_step_tail(const IcpTail &tail, double *__res
     double s = 0.0;
 #pragma unroll
     for (int w = 0; w < ICP_WPB; ++w) s += lds[w][tid];
-    // column-major (sum j of block b at [j * blocks + b]): a group's entries of one column are contiguous
-    st_agent(&partials[(size_t)tid * nblk + blockIdx.x], s);
+    // row-major (sum j of block b at [b * NS + j]): a workgroup's sums are one contiguous 192..320-byte store that no
+    // other workgroup's share a cache line with (column-major, the neighbours of a line came from eight XCDs at once)
+    st_agent(&partials[(size_t)blockIdx.x * NS + tid], s);
   }
   drain_stores();
   __syncthreads();
@@ -358,7 +360,7 @@ __device__ __forceinline__ void icp_step_tail(const IcpTail &tail, double *__res
   for (int c0 = 0; c0 < NS; c0 += 32) {  // 32 columns per round (8 lanes each): one round up to 32 sums
     const int col = c0 + (tid >> 3);
     const bool colth = col < NS;
-    const double s = tail_column_sum(partials + (size_t)(colth ? col : 0) * nblk + (size_t)g * ICP_GROUP, gsize, r, colth);
+    const double s = tail_column_sum(partials + (size_t)g * ICP_GROUP * NS + (colth ? col : 0), gsize, r, colth, NS);
     if (colth && r == 0) st_agent(&tail.gpart[(size_t)col * tail.ngroups + g], s);
   }
   drain_stores();
