@@ -397,9 +397,9 @@ int pclmi_icp_end(pclmi_icp_ctx *ctx, float *aligned);
  *   pclmi_icp_state(ctx, final_T, stats)                  synchronises and reads the state back
  *   pclmi_icp_end(ctx, aligned)
  * pclmi_icp_run_dev enqueues `iterations` iterations, each ONE kernel (step, reduction, exchange with the peers
- * when a communicator is attached, solve).  A shard whose workgroups all fit on the chip at once (up to ~262k
- * points) runs them inside ONE launch - the workgroups wait for the next transform instead of ending; same
- * arithmetic in the same order, bit-identical state.  Such launches of one process reserve their workgroups on the
+ * when a communicator is attached, solve).  A small shard (up to 64 workgroups = 16k points; PCLMI_ICP_LOOP_MAX=<n>
+ * workgroups moves the limit, up to what the chip holds at once, ~262k points) runs them inside ONE launch - the
+ * workgroups wait for the next transform instead of ending; same arithmetic in the same order, bit-identical state.  Such launches of one process reserve their workgroups on the
  * device (a context that does not get them runs one launch per iteration); if other work keeps a launch's
  * workgroups off the chip for more than 5 s, pclmi_icp_state returns PCLMI_ERR_HIP (PCLMI_ICP_LOOP=0 disables
  * the resident form).  The device

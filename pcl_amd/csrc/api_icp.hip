@@ -399,9 +399,21 @@ int pclmi_icp_begin_sharded(const pclmi_tree *target, const float *src, size_t n
 // context reserves its workgroups before its first resident launch and gives them back when the host has waited for
 // its stream (pclmi_icp_state / pclmi_icp_end); a context that does not get them runs one launch per iteration.
 static std::atomic<long long> g_loop_blocks[64];
+// The resident loop is USED up to this many workgroups (16k points).  It was built when a launch per iteration cost a
+// 125k-point shard 8 us more than the kernel ran; since the step's arrival tickets sit in address ranges of their own
+// (kTicketStride) and most points skip the walk, one launch per iteration is as fast or faster from ~30k points up
+// (250k: 22.1 us against 26.0 resident, 125k 18.7 / 19.0, 31k 16.8 / 17.5) and only the smallest shards still gain
+// (15.6k: 15.3 / 13.9, 7.8k 14.0 / 13.1, 977 points 12.3 / 12.0).  PCLMI_ICP_LOOP_MAX=<workgroups> moves the limit
+// (the tests run with 4096: every size the loop fits).  Read on every call: a test may change it.
+static size_t loop_prefer_blocks() {
+  const char *e = getenv("PCLMI_ICP_LOOP_MAX");
+  return e ? (size_t)atoll(e) : (size_t)64;
+}
 static bool loop_reserve(pclmi_icp_ctx *c) {
   if (c->loop_hold) return true;
-  const size_t cap = icp_loop_capacity(c->tree, c->plane), need = icp_step_blocks(c->n);
+  const size_t need = icp_step_blocks(c->n);
+  if (need > loop_prefer_blocks()) return false;
+  const size_t cap = icp_loop_capacity(c->tree, c->plane);
   const int dev = c->tree->device & 63;
   if (need > cap) return false;
   const long long before = g_loop_blocks[dev].fetch_add((long long)need);
