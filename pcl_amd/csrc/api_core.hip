@@ -423,11 +423,11 @@ int tree_ensure_cert(const pclmi_tree *t) {
   t->cert_tried = true;
   PCLMI_HIP(hipSetDevice(t->device));
   const size_t rows = t->rows, n_slots = (size_t)t->M * kLeafSize;
-  DevBuf<int32_t> idx, inv;
-  DevBuf<float> d2;
-  RC(idx.alloc(rows * 3));
-  RC(d2.alloc(rows * 3));
-  RC(inv.alloc(rows));
+  // one block for the three temporaries (hipMalloc / hipFree cost ~0.1-0.5 ms each and hipFree waits for the device)
+  DevBuf<int32_t> tmp;
+  RC(tmp.alloc(rows * 7));
+  struct { int32_t *p; } idx{tmp.p}, inv{tmp.p + rows * 6};
+  struct { float *p; } d2{reinterpret_cast<float *>(tmp.p + rows * 3)};
   float *cert = nullptr;
   PCLMI_HIP(hipMalloc(&cert, n_slots * sizeof(float4)));
   // rows that are not indexed (non-finite, or outside an index view) are searched too; nothing reads their result
