@@ -26,8 +26,10 @@ void set_identity(float *T) {
 }
 
 // host points (strided) -> device float4 (x, y, z, 1), optionally through an index list
+// lo / hi (nullable, with guess nullable): the bounding box of the finite rows after `guess`, taken in the same pass
 int upload_packed(const float *h, size_t n_rows, size_t stride_bytes, const int32_t *rows, size_t n_sel,
-                  DevBuf<float4> &out, hipStream_t s) {
+                  DevBuf<float4> &out, hipStream_t s, float *lo = nullptr, float *hi = nullptr,
+                  const float *guess = nullptr) {
   const size_t n = rows ? n_sel : n_rows;
   std::vector<float4> tmp(n ? n : 1);
   const size_t sf = stride_bytes / 4;
@@ -39,6 +41,17 @@ int upload_packed(const float *h, size_t n_rows, size_t stride_bytes, const int3
     }
     const float *p = h + r * sf;
     tmp[i] = make_float4(p[0], p[1], p[2], 1.f);
+    if (lo) {
+      if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2])) continue;
+      float q[3] = {p[0], p[1], p[2]};
+      if (guess)
+        for (int d = 0; d < 3; ++d)
+          q[d] = guess[d * 4 + 0] * p[0] + guess[d * 4 + 1] * p[1] + guess[d * 4 + 2] * p[2] + guess[d * 4 + 3];
+      for (int d = 0; d < 3; ++d) {
+        lo[d] = std::min(lo[d], q[d]);
+        hi[d] = std::max(hi[d], q[d]);
+      }
+    }
   }
   RC(out.alloc(n));
   if (n) PCLMI_HIP(hipMemcpyAsync(out.p, tmp.data(), n * sizeof(float4), hipMemcpyHostToDevice, s));
@@ -287,23 +300,12 @@ int pclmi_icp_begin_sharded(const pclmi_tree *target, const float *src, size_t n
   int rc;
   // output <- input with w = 1 (registration.hpp:149-163), then the guess (icp.hpp:60-66)
   DevBuf<float4> raw;
-  if ((rc = upload_packed(src, n_src, stride_bytes, nullptr, 0, raw, c->stream))) return fail(rc);
-  if (guess && !is_identity(guess)) launch_transform(raw.p, n_src, make_xf(guess), c->stream);
-  // Morton-cell order over the source's own bounding box
+  // Morton-cell order over the source's own bounding box (taken in the upload's pass over the points)
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-  const size_t sf = stride_bytes / 4;
-  for (size_t i = 0; i < n_src; ++i) {
-    const float *p = src + i * sf;
-    if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2])) continue;
-    float q[3] = {p[0], p[1], p[2]};
-    if (guess && !is_identity(guess))
-      for (int d = 0; d < 3; ++d)
-        q[d] = guess[d * 4 + 0] * p[0] + guess[d * 4 + 1] * p[1] + guess[d * 4 + 2] * p[2] + guess[d * 4 + 3];
-    for (int d = 0; d < 3; ++d) {
-      lo[d] = std::min(lo[d], q[d]);
-      hi[d] = std::max(hi[d], q[d]);
-    }
-  }
+  if ((rc = upload_packed(src, n_src, stride_bytes, nullptr, 0, raw, c->stream, lo, hi,
+                          (guess && !is_identity(guess)) ? guess : nullptr)))
+    return fail(rc);
+  if (guess && !is_identity(guess)) launch_transform(raw.p, n_src, make_xf(guess), c->stream);
   if (!(lo[0] <= hi[0])) lo[0] = lo[1] = lo[2] = hi[0] = hi[1] = hi[2] = 0.f;
   if ((rc = c->pts.alloc(n_src)) || (rc = c->order.alloc(n_src)) || (rc = c->inv.alloc(n_src)) ||
       (rc = c->nn.alloc(n_src)) || (rc = c->nn_slot.alloc(n_src)) || (rc = c->dist.alloc(n_src)) ||
@@ -357,19 +359,7 @@ int pclmi_icp_begin_sharded(const pclmi_tree *target, const float *src, size_t n
       return fail(hip_fail(hipGetLastError(), "inv upload", __FILE__, __LINE__));
   }
   // inv[order[slot]] = slot (RANSAC pair lists)
-  if (!c->sharded) {
-    DevBuf<int> ids;
-    if ((rc = ids.alloc(n_src))) return fail(rc);
-    launch_iota(ids.p, n_src, c->stream);
-    // scatter: reuse unpermute on ints via gather of identity is not possible; do it on the host side of
-    // the API only once per align - cheap relative to the upload
-    std::vector<int> h_order(n_src ? n_src : 1), h_inv(n_src ? n_src : 1);
-    if (n_src && hipMemcpy(h_order.data(), c->order.p, n_src * 4, hipMemcpyDeviceToHost) != hipSuccess)
-      return fail(hip_fail(hipGetLastError(), "order download", __FILE__, __LINE__));
-    for (size_t s = 0; s < n_src; ++s) h_inv[h_order[s]] = (int)s;
-    if (n_src && hipMemcpy(c->inv.p, h_inv.data(), n_src * 4, hipMemcpyHostToDevice) != hipSuccess)
-      return fail(hip_fail(hipGetLastError(), "inv upload", __FILE__, __LINE__));
-  }
+  if (!c->sharded) launch_inverse_permutation(c->order.p, n_src, c->inv.p, c->stream);
   if (c->n && hipMemsetAsync(c->dist.p, 0, c->n * 4, c->stream) != hipSuccess)  // previous distances start at 0
     return fail(hip_fail(hipGetLastError(), "memset", __FILE__, __LINE__));
   // moments are taken about the centre of the target's bounding box: identical on every rank

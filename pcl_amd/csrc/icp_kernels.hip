@@ -2577,6 +2577,14 @@ void launch_gather_u8(const unsigned char *in, const int *idx, size_t n, unsigne
   if (n) hipLaunchKernelGGL(gather_u8_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, in, idx, (int)n, out);
 }
 
+__global__ void inverse_permutation_kernel(const int *__restrict__ order, int n, int *__restrict__ inv) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) inv[order[i]] = i;
+}
+void launch_inverse_permutation(const int *order, size_t n, int *inv, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(inverse_permutation_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, order, (int)n, inv);
+}
+
 void launch_iota(int *v, size_t n, hipStream_t s) {
   if (n) hipLaunchKernelGGL(iota_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, v, (int)n);
 }

@@ -452,6 +452,7 @@ void launch_corr_flags(const int *d_nn, const float4 *d_pts, const float4 *d_clo
                        unsigned char *d_keep_slot = nullptr, const float4 *d_rows = nullptr,
                        const int *d_row_of = nullptr);
 void launch_iota(int *v, size_t n, hipStream_t s);
+void launch_inverse_permutation(const int *order, size_t n, int *inv, hipStream_t s);  // inv[order[i]] = i
 void launch_gather_int(const int *in, const int *idx, size_t n, int *out, hipStream_t s);
 void launch_gather_points(const float4 *a, const int *ia, const float4 *b, const int *ib, const int pos[3],
                           float4 *out, hipStream_t s);
