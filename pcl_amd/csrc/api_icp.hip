@@ -1,4 +1,5 @@
 // api_icp.hip - C ABI: correspondences, rigid-transform estimation, transform, ICP.
+#include <memory>
 #include <algorithm>
 #include <cmath>
 #include <cstddef>
@@ -31,7 +32,9 @@ int upload_packed(const float *h, size_t n_rows, size_t stride_bytes, const int3
                   DevBuf<float4> &out, hipStream_t s, float *lo = nullptr, float *hi = nullptr,
                   const float *guess = nullptr) {
   const size_t n = rows ? n_sel : n_rows;
-  std::vector<float4> tmp(n ? n : 1);
+  // (not a std::vector: its value-initialisation would write the 16 bytes per point once more)
+  std::unique_ptr<float4[]> tmp(new (std::nothrow) float4[n ? n : 1]);
+  PCLMI_CHECK(tmp != nullptr, PCLMI_ERR_OOM, "out of host memory");
   const size_t sf = stride_bytes / 4;
   for (size_t i = 0; i < n; ++i) {
     size_t r = rows ? (size_t)rows[i] : i;
@@ -54,7 +57,7 @@ int upload_packed(const float *h, size_t n_rows, size_t stride_bytes, const int3
     }
   }
   RC(out.alloc(n));
-  if (n) PCLMI_HIP(hipMemcpyAsync(out.p, tmp.data(), n * sizeof(float4), hipMemcpyHostToDevice, s));
+  if (n) PCLMI_HIP(hipMemcpyAsync(out.p, tmp.get(), n * sizeof(float4), hipMemcpyHostToDevice, s));
   PCLMI_HIP(hipStreamSynchronize(s));  // tmp goes out of scope
   return PCLMI_OK;
 }
