@@ -46,7 +46,9 @@ while time.time() < t_end:
         rc, T, out, st = capi.icp_align(tree, src, p)
         rco, To, outo, sto = orc.icp_align(src, tgt, po, nthreads=8)
         assert (rc == 0) == (rco == 0), (rc, rco, len(src))
-        if rc == 0:
+        # (a few dozen pairs with a third of them inliers: the 3-point models' fp32 / fp64 difference decides single
+        #  inliers and the refits part ways - DESIGN 10.9 - although the first iterations agree to the bit)
+        if rc == 0 and min(st.last_correspondences, sto.last_correspondences) >= 200 and st.last_inliers >= 100:
             bad = (st.iterations != sto.iterations or st.last_correspondences != sto.last_correspondences or
                    np.abs(T - To).max() > 2e-5 + 1e-6 * float(np.abs(tgt).max()))  # ~8 ulp of the largest coordinate
             if bad:
