@@ -2058,7 +2058,8 @@ __global__ __launch_bounds__(kSbRows) void ransac_words_draw_kernel(RansacLoopAr
 // countWithinDistance of every model of the batch in one pass over the stored source points (masked by keep_slot),
 // then - in the workgroup that finishes last - the trials are consumed in order under the reference's stopping rule
 __global__ __launch_bounds__(256) void ransac_count_loop_kernel(RansacLoopArgs a, int first) {
-  __shared__ Xf xf[kRansacBatch];
+  // the models in PAIRS: coefficient i of models 2 k and 2 k + 1 side by side, for the packed fp32 instructions below
+  __shared__ f2v xf2[kRansacBatch / 2][12];
   __shared__ int ready[kRansacBatch];
   __shared__ unsigned int cnt[kRansacBatch];
   __shared__ int s_last;
@@ -2067,10 +2068,12 @@ __global__ __launch_bounds__(256) void ransac_count_loop_kernel(RansacLoopArgs a
   if (st->done || !rl->active || rl->settled) return;
   if (first ? st->hold != 0 : st->hold == 0) return;
   const int batch = rl->ntrials;
-  if ((int)threadIdx.x < batch) {
-    const RansacTrial &tr = a.trials[threadIdx.x];
-    for (int i = 0; i < 12; ++i) xf[threadIdx.x].m[i] = tr.T[i];
-    ready[threadIdx.x] = tr.status == 0;
+  if ((int)threadIdx.x < kRansacBatch) {
+    const bool in = (int)threadIdx.x < batch;
+    const RansacTrial &tr = a.trials[in ? threadIdx.x : 0];
+    float *half = reinterpret_cast<float *>(&xf2[threadIdx.x >> 1][0]) + (threadIdx.x & 1);
+    for (int i = 0; i < 12; ++i) half[2 * i] = in ? tr.T[i] : 0.f;
+    ready[threadIdx.x] = in && tr.status == 0;
     cnt[threadIdx.x] = 0u;
   }
   __syncthreads();
@@ -2086,13 +2089,30 @@ __global__ __launch_bounds__(256) void ransac_count_loop_kernel(RansacLoopArgs a
         p = a.pts[i];
         q = a.tq[i];
       }
-      for (int b = 0; b < batch; ++b) {
-        if (!ready[b]) continue;  // block-uniform
-        const float4 m = apply_xf(xf[b], p);
-        const float dx = m.x - q.x, dy = m.y - q.y, dz = m.z - q.z;
-        const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-        const unsigned int c = (unsigned int)__popcll(__ballot(live && (double)d < a.inlier_thr2));
-        if (lane == b) mine += c;
+      // two models per instruction (v_pk_mul_f32 / v_pk_add_f32: each half an ordinary IEEE fp32 operation, so the
+      // distances are apply_xf's and the scalar expression's to the bit): the kernel is bound by its VALU work
+      const f2v px = {p.x, p.x}, py = {p.y, p.y}, pz = {p.z, p.z};
+      const f2v qx = {q.x, q.x}, qy = {q.y, q.y}, qz = {q.z, q.z};
+      for (int b = 0; b < batch; b += 2) {
+        if (!ready[b] && !ready[b + 1]) continue;  // block-uniform
+        const f2v *T = xf2[b >> 1];
+        f2v d;
+        {
+#pragma clang fp contract(off)
+          const f2v mx = ((T[0] * px + T[1] * py) + T[2] * pz) + T[3];
+          const f2v my = ((T[4] * px + T[5] * py) + T[6] * pz) + T[7];
+          const f2v mz = ((T[8] * px + T[9] * py) + T[10] * pz) + T[11];
+          const f2v dx = mx - qx, dy = my - qy, dz = mz - qz;
+          d = (dx * dx + dy * dy) + dz * dz;
+        }
+        if (ready[b]) {
+          const unsigned int c = (unsigned int)__popcll(__ballot(live && (double)d.x < a.inlier_thr2));
+          if (lane == b) mine += c;
+        }
+        if (ready[b + 1]) {
+          const unsigned int c = (unsigned int)__popcll(__ballot(live && (double)d.y < a.inlier_thr2));
+          if (lane == b + 1) mine += c;
+        }
       }
     }
     if (lane < batch && mine) atomicAdd(&cnt[lane], mine);
