@@ -789,7 +789,7 @@ def bench_extras(env, tree, target, q_host, q_dev, stream):
         p = capi.icp_default_params()
         p.ransac_iterations, p.max_correspondence_distance = 0, 25.0
         times = {}
-        for iters_pl in (2, 2, 22, 2, 22, 2, 22):  # best of three each: the set-up (upload, ordering) jitters by a few %
+        for iters_pl in (2, 2, 22, 2, 22, 2, 22, 2, 22, 2, 22):  # best of five each: the set-up (upload, ordering) jitters by a few %
             p.max_iterations = iters_pl
             t0 = time.perf_counter()
             rc, Tpl, _, stpl = capi.icp_align_point_to_plane(t2, src, tn, p)
